@@ -29,7 +29,7 @@ REF = "/root/reference/three_party/Janus/janus/models"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 TINY = dict(hidden=256, inter=512, n_layers=2, n_heads=2, head_dim=128, vocab=512,
-            img_vocab=256, img_dim=8, grid=4, gen_head_dim=256, vq_ch=64,
+            img_vocab=256, img_dim=8, grid=8, gen_head_dim=256, vq_ch=64,
             vq_ch_mult=(1, 2, 2), vq_z=64, eos_id=7, pad_id=3)
 
 

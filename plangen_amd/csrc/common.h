@@ -1,0 +1,110 @@
+// Device-side helpers shared by all kernels.  gfx950 (MI355X / CDNA4) only: wave = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define WAVE 64
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) ------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b16) { return __uint_as_float(b16 << 16); }
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN -> quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+
+// Element-type traits: T = float (PG_F32 mode) or bf16 (PG_BF16 mode).
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static constexpr int EPV = 4;                  // elements per 16-byte vector
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    // unpack a 16-byte vector into EPV floats
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y);
+        f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 v; v.x = __float_as_uint(f[0]); v.y = __float_as_uint(f[1]);
+        v.z = __float_as_uint(f[2]); v.w = __float_as_uint(f[3]); return v;
+    }
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <> struct ET<bf16> {
+    static constexpr int EPV = 8;
+    __device__ static __forceinline__ float ld(const bf16* p) {
+        return bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(p));
+    }
+    __device__ static __forceinline__ void st(bf16* p, float v) {
+        *reinterpret_cast<uint16_t*>(p) = (uint16_t)f32_to_bf16_bits(v);
+    }
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x); f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+        f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z); f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 v; v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+        v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]); return v;
+    }
+    __device__ static __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+};
+
+// ---- wave / block reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Sum over a block of NW waves; every thread gets the result.  ``red`` >= NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float swish_precise(float x) { return x / (1.f + expf(-x)); }
+
+// XCD-aware block remap (MI355X: 8 XCDs, block b lands on XCD b%8): give each XCD a
+// contiguous chunk of the logical tile space so neighbouring tiles share one L2.
+// Bijective for any nb (cdna guide T1).
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// Counter-based RNG (splitmix64 finaliser) -> uniform (0,1)
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t a, uint64_t b) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xBF58476D1CE4E5B9ull * (b + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+}

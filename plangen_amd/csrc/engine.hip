@@ -1,0 +1,1094 @@
+// Host side of libplangen_hip.so: the engine behind include/plangen_hip.h.
+// One engine per (process, GPU).  Owns weights (converted to the compute dtype and to the
+// layouts the kernels want), the KV cache [layer][K|V][row][head][slot][128], workspaces,
+// and the decode-step hipGraph.  No torch types anywhere: plain pointers and sizes.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/plangen_hip.h"
+#include "kernels.h"
+
+static thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            char _b[512];                                                                                \
+            snprintf(_b, sizeof _b, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            this->err = _b;                                                                              \
+            return PG_ERR_HIP;                                                                           \
+        }                                                                                                \
+    } while (0)
+#define FAIL(code, ...)                       \
+    do {                                      \
+        char _b[512];                         \
+        snprintf(_b, sizeof _b, __VA_ARGS__); \
+        this->err = _b;                       \
+        return code;                          \
+    } while (0)
+#define TRY(expr)                  \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != PG_OK) return _rc; \
+    } while (0)
+
+enum SlotKind { K_T = 0, K_F32, K_IL16_G, K_IL16_U, K_CONV };
+struct Slot {
+    void* dst = nullptr; SlotKind kind = K_T; long n = 0;
+    int a = 0, b = 0, c = 0;
+    bool loaded = false;
+};
+struct ConvW { void* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 3; };
+struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; };
+struct ResBlockW { NormW n1, n2; ConvW c1, c2, nin; bool has_nin = false; };
+struct AttnW { NormW n; ConvW q, k, v, p; };
+struct VqLevel { std::vector<ResBlockW> res; std::vector<AttnW> attn; ConvW resample; bool has_resample = false; };
+struct VqNet { ConvW conv_in; ResBlockW mid0, mid2; AttnW mid1; std::vector<VqLevel> levels; NormW norm_out; ConvW conv_out; };
+
+struct pg_engine {
+    pg_config cfg{};
+    int dev = 0;
+    bool bf = true;
+    size_t esz = 2;
+    std::string err;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    std::map<std::string, Slot> slots_map;
+
+    // ---- weights
+    struct Layer { void *wqkv, *wo, *wgu, *wd, *ln1, *ln2; };
+    std::vector<Layer> layers;
+    void* norm_w = nullptr; float* embed = nullptr; void* lm_head = nullptr;
+    void *gh_w1 = nullptr, *gh_w2 = nullptr; float *gh_b1 = nullptr, *gh_b2 = nullptr;
+    float *ge_w = nullptr, *al_w0 = nullptr, *al_b0 = nullptr, *al_w2 = nullptr, *al_b2 = nullptr;
+    float* gen_table = nullptr;
+    float *codebook = nullptr, *codebook_n = nullptr, *pq_w = nullptr, *pq_b = nullptr;
+    void* pq_table = nullptr;
+    void* qc_w = nullptr; float* qc_b = nullptr;                 // encoder quant_conv (z -> img_dim)
+    float *enc_in_w = nullptr, *enc_in_b = nullptr;              // encoder conv_in (3 -> ch), fp32 [Cout][3][3][3]
+    VqNet dec, enc;
+    float *cos_t = nullptr, *sin_t = nullptr; int max_pos = 0;
+    void* zeros = nullptr;
+    bool finalized = false;
+
+    // ---- sequence state
+    int R = 0, L = 0, Ntok = 0, slots = 0; bool prefilled = false; int pos_mode = 0;
+    int n_dec_host = 0;
+    std::vector<int> h_len;
+    int32_t *d_len = nullptr, *d_pos_off = nullptr, *d_ndec = nullptr, *d_tok_row = nullptr, *d_tok_j = nullptr,
+            *d_tok_src = nullptr, *d_last = nullptr, *d_unf = nullptr, *d_anyunf = nullptr;
+    int32_t* h_stage = nullptr;                                  // pinned host staging
+    void* kv = nullptr;
+    // ---- workspaces
+    long max_tok = 0;
+    float* x = nullptr; void* xn = nullptr; float* part = nullptr; long part_elems = 0;
+    void *qbuf = nullptr, *obuf = nullptr, *hbuf = nullptr, *hfin = nullptr, *gh_in = nullptr, *gh_mid = nullptr;
+    // VQ: cur / t1 / t2 / t3 rotate through vbuf
+    void* vbuf[4] = {nullptr, nullptr, nullptr, nullptr}; long vbuf_elems = 0;
+    void *cur = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
+    void *aq = nullptr, *ak = nullptr, *avt = nullptr, *ao = nullptr, *ap = nullptr; float* ascore = nullptr;
+    float *gn_stats = nullptr, *gn_ws = nullptr;
+    float* enc_z = nullptr;
+    void* stage_dev = nullptr; long stage_bytes = 0;
+    // ---- streams / graph / timing
+    hipStream_t istream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr, ev_v0 = nullptr, ev_v1 = nullptr;
+    hipGraphExec_t gexec = nullptr; std::vector<int64_t> gkey;
+    bool use_graph = true; bool time_attn = false;
+    std::vector<hipEvent_t> attn_ev; size_t attn_ev_used = 0; std::vector<double> attn_ev_bytes;
+    pg_timing timing{};
+    bool have_decode_t = false, have_prefill_t = false, have_vq_t = false;
+    int S_last = 1; long slab_last = 0;
+
+    template <typename U> int dalloc(U** p, size_t n_bytes) {
+        void* q = nullptr;
+        if (n_bytes == 0) n_bytes = 16;
+        HIPCHK(hipMalloc(&q, n_bytes));
+        allocs.push_back(q); bytes += (int64_t)n_bytes; *p = (U*)q;
+        return PG_OK;
+    }
+    int H() const { return cfg.hidden; }
+    int HD() const { return cfg.n_heads * cfg.head_dim; }
+    int img_tokens() const { return cfg.grid * cfg.grid; }
+    int img_size() const { return cfg.grid << (cfg.vq_levels - 1); }
+    size_t kv_layer_elems() const { return (size_t)cfg.max_rows * cfg.n_heads * slots * 128; }
+    void* kc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 0) * kv_layer_elems() * esz; }
+    void* vc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 1) * kv_layer_elems() * esz; }
+    SeqState seq() const { return SeqState{d_len, d_pos_off, d_ndec, d_tok_row, d_tok_j}; }
+
+    int create();
+    void add_slot(const std::string& name, void* dst, SlotKind k, long n, int a = 0, int b = 0, int c = 0);
+    int alloc_conv(const std::string& name, ConvW& cw, int cout, int cin, int k);
+    int alloc_norm(const std::string& name, NormW& nw, int c);
+    int alloc_res(const std::string& name, ResBlockW& r, int cin, int cout);
+    int alloc_attn(const std::string& name, AttnW& a, int c);
+    int build_vq();
+    int load_tensor(const char* name, const void* src, int dtype, const int64_t* shape, int ndim);
+    int finalize(int* missing, hipStream_t s);
+    int prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtype, const int32_t* pad_len, int R_, int L_,
+                int pmode, void* hidden_out, int hidden_dtype, hipStream_t s);
+    template <typename T> void gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, int K, bool allow_skinny);
+    template <typename T> void run_layers(hipStream_t s, int M, int mode, T* final_out);
+    template <typename T> void head_logits(hipStream_t s, const T* in, int M);
+    void forward_decode(hipStream_t s);
+    int decode_image(int T, float cfgw, float temp, uint64_t seed, const int32_t* force_tok, const uint8_t* force_mask,
+                     int32_t* out_tok, float* logits_out, hipStream_t s);
+    int step(const void* emb, int emb_dtype, void* hidden_out, int hidden_dtype, hipStream_t s);
+    int gen_head(const void* h_dev, int h_dtype, float* logits, int R_, hipStream_t s);
+    int text_greedy(int max_new, int min_new, int eos, int64_t* out, int* out_len, hipStream_t s);
+    template <typename T> int vq_decode(const int32_t* codes, void* img_out, int out_dtype, int B, hipStream_t s);
+    template <typename T> int vq_encode(const void* img, int img_dtype, int64_t* idx, int B, hipStream_t s);
+    template <typename T> void conv3(hipStream_t s, const ConvW& cw, const T* in, T* out, const T* residual, int B, int Hi, int Wi, int up, int stride2);
+    template <typename T> void conv1(hipStream_t s, const ConvW& cw, const T* in, T* out, const T* residual, long M);
+    template <typename T> void resblock(hipStream_t s, const ResBlockW& r, int B, int Hs, int Ws);
+    template <typename T> void attnblock(hipStream_t s, const AttnW& a, int B, int HW);
+    template <typename T> void gn(hipStream_t s, const NormW& n, const T* in, T* out, int B, int HW, int swish);
+    int fetch_timing();
+    void destroy();
+};
+
+// =============================================================================== create
+void pg_engine::add_slot(const std::string& name, void* dst, SlotKind k, long n, int a, int b, int c) {
+    Slot s; s.dst = dst; s.kind = k; s.n = n; s.a = a; s.b = b; s.c = c;
+    slots_map[name] = s;
+}
+int pg_engine::alloc_conv(const std::string& name, ConvW& cw, int cout, int cin, int k) {
+    cw.cin = cin; cw.cout = cout; cw.k = k;
+    TRY(dalloc(&cw.w, (size_t)cout * cin * k * k * esz));
+    TRY(dalloc(&cw.b, (size_t)cout * 4));
+    add_slot(name + ".weight", cw.w, k == 1 ? K_T : K_CONV, (long)cout * cin * k * k, cout, cin, k * k);
+    add_slot(name + ".bias", cw.b, K_F32, cout);
+    return PG_OK;
+}
+int pg_engine::alloc_norm(const std::string& name, NormW& nw, int c) {
+    nw.c = c;
+    TRY(dalloc(&nw.g, (size_t)c * 4));
+    TRY(dalloc(&nw.b, (size_t)c * 4));
+    add_slot(name + ".weight", nw.g, K_F32, c);
+    add_slot(name + ".bias", nw.b, K_F32, c);
+    return PG_OK;
+}
+int pg_engine::alloc_res(const std::string& name, ResBlockW& r, int cin, int cout) {
+    TRY(alloc_norm(name + ".norm1", r.n1, cin));
+    TRY(alloc_conv(name + ".conv1", r.c1, cout, cin, 3));
+    TRY(alloc_norm(name + ".norm2", r.n2, cout));
+    TRY(alloc_conv(name + ".conv2", r.c2, cout, cout, 3));
+    r.has_nin = cin != cout;
+    if (r.has_nin) TRY(alloc_conv(name + ".nin_shortcut", r.nin, cout, cin, 1));
+    return PG_OK;
+}
+int pg_engine::alloc_attn(const std::string& name, AttnW& a, int c) {
+    TRY(alloc_norm(name + ".norm", a.n, c));
+    TRY(alloc_conv(name + ".q", a.q, c, c, 1));
+    TRY(alloc_conv(name + ".k", a.k, c, c, 1));
+    TRY(alloc_conv(name + ".v", a.v, c, c, 1));
+    TRY(alloc_conv(name + ".proj_out", a.p, c, c, 1));
+    return PG_OK;
+}
+
+// Decoder / Encoder structure: vq_model.py:127-187 / :48-103.
+int pg_engine::build_vq() {
+    const int nres = cfg.vq_levels, ch = cfg.vq_ch;
+    const std::string V = "gen_vision_model.";
+    {
+        const std::string D = V + "decoder.";
+        int block_in = ch * cfg.vq_ch_mult[nres - 1];
+        TRY(alloc_conv(D + "conv_in", dec.conv_in, block_in, cfg.vq_z, 3));
+        TRY(alloc_res(D + "mid.0", dec.mid0, block_in, block_in));
+        TRY(alloc_attn(D + "mid.1", dec.mid1, block_in));
+        TRY(alloc_res(D + "mid.2", dec.mid2, block_in, block_in));
+        dec.levels.resize(nres);
+        for (int bi = 0; bi < nres; ++bi) {
+            const int i_level = nres - 1 - bi;
+            const int block_out = ch * cfg.vq_ch_mult[i_level];
+            VqLevel& lv = dec.levels[bi];
+            lv.res.resize(cfg.vq_res_blocks + 1);
+            if (i_level == nres - 1) lv.attn.resize(cfg.vq_res_blocks + 1);
+            const std::string p = D + "conv_blocks." + std::to_string(bi);
+            for (int j = 0; j < cfg.vq_res_blocks + 1; ++j) {
+                TRY(alloc_res(p + ".res." + std::to_string(j), lv.res[j], block_in, block_out));
+                block_in = block_out;
+                if (i_level == nres - 1) TRY(alloc_attn(p + ".attn." + std::to_string(j), lv.attn[j], block_in));
+            }
+            if (i_level != 0) {
+                lv.has_resample = true;
+                TRY(alloc_conv(p + ".upsample.conv", lv.resample, block_in, block_in, 3));
+            }
+        }
+        TRY(alloc_norm(D + "norm_out", dec.norm_out, block_in));
+        TRY(alloc_conv(D + "conv_out", dec.conv_out, 3, block_in, 3));
+    }
+    if (cfg.with_vq_encoder) {
+        const std::string E = V + "encoder.";
+        TRY(dalloc(&enc_in_w, (size_t)ch * 27 * 4));
+        TRY(dalloc(&enc_in_b, (size_t)ch * 4));
+        add_slot(E + "conv_in.weight", enc_in_w, K_F32, (long)ch * 27);
+        add_slot(E + "conv_in.bias", enc_in_b, K_F32, ch);
+        enc.levels.resize(nres);
+        int b_in = ch;
+        for (int lvl = 0; lvl < nres; ++lvl) {
+            const int b_out = ch * cfg.vq_ch_mult[lvl];
+            VqLevel& lv = enc.levels[lvl];
+            lv.res.resize(cfg.vq_res_blocks);
+            if (lvl == nres - 1) lv.attn.resize(cfg.vq_res_blocks);
+            const std::string p = E + "conv_blocks." + std::to_string(lvl);
+            for (int j = 0; j < cfg.vq_res_blocks; ++j) {
+                TRY(alloc_res(p + ".res." + std::to_string(j), lv.res[j], b_in, b_out));
+                b_in = b_out;
+                if (lvl == nres - 1) TRY(alloc_attn(p + ".attn." + std::to_string(j), lv.attn[j], b_in));
+            }
+            if (lvl != nres - 1) {
+                lv.has_resample = true;
+                TRY(alloc_conv(p + ".downsample.conv", lv.resample, b_in, b_in, 3));
+            }
+        }
+        TRY(alloc_res(E + "mid.0", enc.mid0, b_in, b_in));
+        TRY(alloc_attn(E + "mid.1", enc.mid1, b_in));
+        TRY(alloc_res(E + "mid.2", enc.mid2, b_in, b_in));
+        TRY(alloc_norm(E + "norm_out", enc.norm_out, b_in));
+        TRY(alloc_conv(E + "conv_out", enc.conv_out, cfg.vq_z, b_in, 3));
+        TRY(dalloc(&qc_w, (size_t)cfg.img_dim * cfg.vq_z * esz));
+        TRY(dalloc(&qc_b, (size_t)cfg.img_dim * 4));
+        add_slot(V + "quant_conv.weight", qc_w, K_T, (long)cfg.img_dim * cfg.vq_z);
+        add_slot(V + "quant_conv.bias", qc_b, K_F32, cfg.img_dim);
+    }
+    return PG_OK;
+}
+
+int pg_engine::create() {
+    bf = cfg.compute_dtype == PG_BF16;
+    esz = bf ? 2 : 4;
+    if (cfg.head_dim != 128) FAIL(PG_ERR_ARG, "head_dim must be 128 (got %d)", cfg.head_dim);
+    if (cfg.hidden % 128 || cfg.inter % 128 || cfg.gen_head_dim % 128)
+        FAIL(PG_ERR_ARG, "hidden/inter/gen_head_dim must be multiples of 128");
+    if (cfg.vocab < 1 || cfg.img_vocab % 16) FAIL(PG_ERR_ARG, "img_vocab must be a multiple of 16");
+    if (cfg.img_dim > 8 || cfg.img_dim < 1) FAIL(PG_ERR_ARG, "img_dim must be in [1,8]");
+    if (cfg.vq_levels < 1 || cfg.vq_levels > PG_MAX_VQ_LEVELS) FAIL(PG_ERR_ARG, "vq_levels");
+    if (cfg.vq_ch % 64 || cfg.vq_z % 64) FAIL(PG_ERR_ARG, "vq_ch / vq_z must be multiples of 64");
+    if (bf && (cfg.grid * cfg.grid) % 64) FAIL(PG_ERR_ARG, "bf16 mode needs grid^2 %% 64 == 0 (AttnBlock GEMM K)");
+    if (cfg.max_rows < 1 || cfg.max_prompt < 1 || cfg.max_new < 1 || cfg.max_images < 1) FAIL(PG_ERR_ARG, "capacities must be >= 1");
+    if (cfg.max_new > 1000 && cfg.with_lm_head) FAIL(PG_ERR_ARG, "max_new <= 1000 with lm_head");
+    HIPCHK(hipSetDevice(dev));
+    const int Hh = H(), I = cfg.inter, HDm = HD();
+    const std::string LM = "language_model.model.";
+    TRY(dalloc(&embed, (size_t)cfg.vocab * Hh * 4));
+    add_slot(LM + "embed_tokens.weight", embed, K_F32, (long)cfg.vocab * Hh);
+    layers.resize(cfg.n_layers);
+    for (int i = 0; i < cfg.n_layers; ++i) {
+        Layer& ly = layers[i];
+        TRY(dalloc(&ly.wqkv, (size_t)3 * HDm * Hh * esz));
+        TRY(dalloc(&ly.wo, (size_t)Hh * HDm * esz));
+        TRY(dalloc(&ly.wgu, (size_t)2 * I * Hh * esz));
+        TRY(dalloc(&ly.wd, (size_t)Hh * I * esz));
+        TRY(dalloc(&ly.ln1, (size_t)Hh * esz));
+        TRY(dalloc(&ly.ln2, (size_t)Hh * esz));
+        const std::string p = LM + "layers." + std::to_string(i) + ".";
+        add_slot(p + "self_attn.q_proj.weight", ly.wqkv, K_T, (long)HDm * Hh);
+        add_slot(p + "self_attn.k_proj.weight", (char*)ly.wqkv + (size_t)HDm * Hh * esz, K_T, (long)HDm * Hh);
+        add_slot(p + "self_attn.v_proj.weight", (char*)ly.wqkv + (size_t)2 * HDm * Hh * esz, K_T, (long)HDm * Hh);
+        add_slot(p + "self_attn.o_proj.weight", ly.wo, K_T, (long)Hh * HDm);
+        add_slot(p + "mlp.gate_proj.weight", ly.wgu, K_IL16_G, (long)I * Hh, I, Hh);
+        add_slot(p + "mlp.up_proj.weight", ly.wgu, K_IL16_U, (long)I * Hh, I, Hh);
+        add_slot(p + "mlp.down_proj.weight", ly.wd, K_T, (long)Hh * I);
+        add_slot(p + "input_layernorm.weight", ly.ln1, K_T, Hh);
+        add_slot(p + "post_attention_layernorm.weight", ly.ln2, K_T, Hh);
+    }
+    TRY(dalloc(&norm_w, (size_t)Hh * esz));
+    add_slot(LM + "norm.weight", norm_w, K_T, Hh);
+    if (cfg.with_lm_head) {
+        TRY(dalloc(&lm_head, (size_t)cfg.vocab * Hh * esz));
+        add_slot("language_model.lm_head.weight", lm_head, K_T, (long)cfg.vocab * Hh);
+    }
+    const int G = cfg.gen_head_dim, V = cfg.img_vocab, Dm = cfg.img_dim;
+    TRY(dalloc(&gh_w1, (size_t)G * Hh * esz));
+    TRY(dalloc(&gh_b1, (size_t)G * 4));
+    TRY(dalloc(&gh_w2, (size_t)V * G * esz));
+    TRY(dalloc(&gh_b2, (size_t)V * 4));
+    add_slot("gen_head.output_mlp_projector.weight", gh_w1, K_T, (long)G * Hh);
+    add_slot("gen_head.output_mlp_projector.bias", gh_b1, K_F32, G);
+    add_slot("gen_head.vision_head.weight", gh_w2, K_T, (long)V * G);
+    add_slot("gen_head.vision_head.bias", gh_b2, K_F32, V);
+    TRY(dalloc(&ge_w, (size_t)V * Dm * 4));
+    TRY(dalloc(&al_w0, (size_t)Hh * Dm * 4));
+    TRY(dalloc(&al_b0, (size_t)Hh * 4));
+    TRY(dalloc(&al_w2, (size_t)Hh * Hh * 4));
+    TRY(dalloc(&al_b2, (size_t)Hh * 4));
+    add_slot("gen_embed.weight", ge_w, K_F32, (long)V * Dm);
+    add_slot("gen_aligner.layers.0.weight", al_w0, K_F32, (long)Hh * Dm);
+    add_slot("gen_aligner.layers.0.bias", al_b0, K_F32, Hh);
+    add_slot("gen_aligner.layers.2.weight", al_w2, K_F32, (long)Hh * Hh);
+    add_slot("gen_aligner.layers.2.bias", al_b2, K_F32, Hh);
+    TRY(dalloc(&gen_table, (size_t)V * Hh * 4));
+    TRY(dalloc(&codebook, (size_t)V * Dm * 4));
+    TRY(dalloc(&codebook_n, (size_t)V * Dm * 4));
+    TRY(dalloc(&pq_w, (size_t)cfg.vq_z * Dm * 4));
+    TRY(dalloc(&pq_b, (size_t)cfg.vq_z * 4));
+    TRY(dalloc(&pq_table, (size_t)V * cfg.vq_z * esz));
+    add_slot("gen_vision_model.quantize.embedding.weight", codebook, K_F32, (long)V * Dm);
+    add_slot("gen_vision_model.post_quant_conv.weight", pq_w, K_F32, (long)cfg.vq_z * Dm);
+    add_slot("gen_vision_model.post_quant_conv.bias", pq_b, K_F32, cfg.vq_z);
+    TRY(build_vq());
+
+    // ---- state + workspaces
+    slots = cfg.max_prompt + cfg.max_new;
+    max_pos = 2 * cfg.max_prompt + cfg.max_new + 64;
+    max_tok = (long)cfg.max_rows * cfg.max_prompt;
+    TRY(dalloc(&kv, (size_t)cfg.n_layers * 2 * kv_layer_elems() * esz));
+    TRY(dalloc(&cos_t, (size_t)max_pos * 64 * 4));
+    TRY(dalloc(&sin_t, (size_t)max_pos * 64 * 4));
+    TRY(dalloc(&zeros, 1024));
+    HIPCHK(hipMemset(zeros, 0, 1024));
+    TRY(dalloc(&d_len, (size_t)cfg.max_rows * 4));
+    TRY(dalloc(&d_pos_off, (size_t)cfg.max_rows * 4));
+    TRY(dalloc(&d_last, (size_t)cfg.max_rows * 4));
+    TRY(dalloc(&d_unf, (size_t)cfg.max_rows * 4));
+    TRY(dalloc(&d_anyunf, 1024 * 4));
+    TRY(dalloc(&d_ndec, 64));
+    HIPCHK(hipMemset(d_ndec, 0, 64));
+    TRY(dalloc(&d_tok_row, (size_t)max_tok * 4));
+    TRY(dalloc(&d_tok_j, (size_t)max_tok * 4));
+    TRY(dalloc(&d_tok_src, (size_t)max_tok * 4));
+    HIPCHK(hipHostMalloc((void**)&h_stage, (size_t)(3 * max_tok + 4 * cfg.max_rows + 16) * 4));
+    TRY(dalloc(&x, (size_t)max_tok * Hh * 4));
+    TRY(dalloc(&xn, (size_t)max_tok * Hh * esz));
+    long pn = 3L * HDm; if (2L * I > pn) pn = 2L * I; if (Hh > pn) pn = Hh;
+    part_elems = max_tok * pn;
+    {   // decode-time split-K slabs can exceed the prefill need when max_tok is small
+        const long rows = cfg.max_rows;
+        long need = 0;
+        auto upd = [&](long N, long K) {
+            long S = (K % 128 == 0) ? skinny_pick_splits((int)N, (int)K) : 1;
+            if (S * rows * N > need) need = S * rows * N;
+        };
+        upd(3L * HDm, Hh); upd(Hh, HDm); upd(2L * I, Hh); upd(Hh, I); upd(G, Hh); upd(V, G);
+        if (cfg.with_lm_head) upd(cfg.vocab, Hh);
+        if (need > part_elems) part_elems = need;
+    }
+    TRY(dalloc(&part, (size_t)part_elems * 4));
+    TRY(dalloc(&qbuf, (size_t)max_tok * HDm * esz));
+    TRY(dalloc(&obuf, (size_t)max_tok * HDm * esz));
+    TRY(dalloc(&hbuf, (size_t)max_tok * I * esz));
+    TRY(dalloc(&hfin, (size_t)cfg.max_rows * Hh * esz));
+    TRY(dalloc(&gh_in, (size_t)cfg.max_rows * Hh * esz));
+    TRY(dalloc(&gh_mid, (size_t)cfg.max_rows * G * esz));
+    {   // VQ activations: largest tensor of the decoder / encoder schedule
+        long mx = 0;
+        const int nres = cfg.vq_levels;
+        for (int lvl = 0; lvl < nres; ++lvl) {
+            const long side = (long)cfg.grid << (nres - 1 - lvl);
+            long c = (long)cfg.vq_ch * cfg.vq_ch_mult[lvl];
+            if (lvl + 1 < nres && (long)cfg.vq_ch * cfg.vq_ch_mult[lvl + 1] > c) c = (long)cfg.vq_ch * cfg.vq_ch_mult[lvl + 1];
+            if (side * side * c > mx) mx = side * side * c;
+        }
+        const long g2 = (long)cfg.grid * cfg.grid;
+        if (g2 * cfg.vq_z > mx) mx = g2 * cfg.vq_z;
+        vbuf_elems = mx * cfg.max_images;
+        for (int i = 0; i < 4; ++i) TRY(dalloc(&vbuf[i], (size_t)vbuf_elems * esz));
+        const long cm = (long)cfg.vq_ch * cfg.vq_ch_mult[nres - 1];
+        const long ab = (long)cfg.max_images * g2 * cm;
+        TRY(dalloc(&aq, (size_t)ab * esz));
+        TRY(dalloc(&ak, (size_t)ab * esz));
+        TRY(dalloc(&avt, (size_t)ab * esz));
+        TRY(dalloc(&ao, (size_t)ab * esz));
+        TRY(dalloc(&ap, (size_t)cfg.max_images * g2 * g2 * esz));
+        TRY(dalloc(&ascore, (size_t)cfg.max_images * g2 * g2 * 4));
+        TRY(dalloc(&gn_stats, (size_t)cfg.max_images * 64 * 4));
+        TRY(dalloc(&gn_ws, (size_t)cfg.max_images * 64 * 4 * 256));
+        if (cfg.with_vq_encoder) TRY(dalloc(&enc_z, (size_t)cfg.max_images * g2 * 8 * 4));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&istream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
+    HIPCHK(hipEventCreate(&ev_p0)); HIPCHK(hipEventCreate(&ev_p1));
+    HIPCHK(hipEventCreate(&ev_v0)); HIPCHK(hipEventCreate(&ev_v1));
+    const char* ng = getenv("PG_NO_GRAPH");
+    if (ng && ng[0] == '1') use_graph = false;
+    return PG_OK;
+}
+
+void pg_engine::destroy() {
+    (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    for (void* p : allocs) (void)hipFree(p);
+    if (stage_dev) (void)hipFree(stage_dev);
+    if (h_stage) (void)hipHostFree(h_stage);
+    for (hipEvent_t e : attn_ev) (void)hipEventDestroy(e);
+    hipEvent_t evs[] = {ev_in, ev_out, ev_t0, ev_t1, ev_p0, ev_p1, ev_v0, ev_v1};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    if (istream) (void)hipStreamDestroy(istream);
+}
+
+// =============================================================================== weights
+int pg_engine::load_tensor(const char* name_c, const void* src, int dtype, const int64_t* shape, int ndim) {
+    std::string name = name_c;
+    if (name.rfind("vl_gpt.", 0) == 0) name = name.substr(7);
+    auto it = slots_map.find(name);
+    if (it == slots_map.end()) FAIL(PG_ERR_NAME, "unknown tensor '%s'", name.c_str());
+    Slot& sl = it->second;
+    long n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i];
+    if (n != sl.n) FAIL(PG_ERR_ARG, "tensor '%s': %ld elements, expected %ld", name.c_str(), n, sl.n);
+    if (dtype != PG_F32 && dtype != PG_BF16) FAIL(PG_ERR_ARG, "tensor '%s': dtype must be f32/bf16", name.c_str());
+    HIPCHK(hipSetDevice(dev));
+    const long nbytes = n * (dtype == PG_BF16 ? 2 : 4);
+    if (nbytes > stage_bytes) {
+        if (stage_dev) { (void)hipFree(stage_dev); bytes -= stage_bytes; }
+        stage_bytes = nbytes < (64L << 20) ? (64L << 20) : nbytes;
+        HIPCHK(hipMalloc(&stage_dev, stage_bytes)); bytes += stage_bytes;
+    }
+    HIPCHK(hipMemcpy(stage_dev, src, nbytes, hipMemcpyHostToDevice));
+    const int sb = dtype == PG_BF16;
+    hipStream_t s = nullptr;
+    switch (sl.kind) {
+        case K_F32: launch_to_f32(s, stage_dev, sb, (float*)sl.dst, n); break;
+        case K_T:
+            if (bf) launch_convert<bf16>(s, stage_dev, sb, (bf16*)sl.dst, n);
+            else launch_convert<float>(s, stage_dev, sb, (float*)sl.dst, n);
+            break;
+        case K_IL16_G: case K_IL16_U: {
+            const int which = sl.kind == K_IL16_U;
+            if (bf) launch_convert_interleave16<bf16>(s, stage_dev, sb, (bf16*)sl.dst, sl.a, sl.b, which);
+            else launch_convert_interleave16<float>(s, stage_dev, sb, (float*)sl.dst, sl.a, sl.b, which);
+            break;
+        }
+        case K_CONV:
+            if (bf) launch_convert_conv<bf16>(s, stage_dev, sb, (bf16*)sl.dst, sl.a, sl.b, sl.c);
+            else launch_convert_conv<float>(s, stage_dev, sb, (float*)sl.dst, sl.a, sl.b, sl.c);
+            break;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    sl.loaded = true;
+    finalized = false;
+    return PG_OK;
+}
+
+int pg_engine::finalize(int* missing, hipStream_t s) {
+    int miss = 0;
+    for (auto& kvp : slots_map)
+        if (!kvp.second.loaded) { if (!miss) err = "missing tensor: " + kvp.first; ++miss; }
+    if (missing) *missing = miss;
+    HIPCHK(hipSetDevice(dev));
+    const int Hh = H(), V = cfg.img_vocab, Dm = cfg.img_dim;
+    {   // gen_table[v] = gen_aligner(gen_embed[v])  (modeling_vlm.py:270-271; projector.py:38-44), fp32
+        float* tmp = nullptr;
+        HIPCHK(hipMalloc((void**)&tmp, (size_t)V * Hh * 4));
+        GemmA a; a.ptr = ge_w; a.lda = Dm;
+        GemmEpi e; e.out = tmp; e.out_f32 = 1; e.ldc = Hh; e.bias_n = al_b0; e.act = 1;
+        launch_gemm<float>(s, a, al_w0, Dm, 0, e, V, Hh, Dm, 1);
+        GemmA a2; a2.ptr = tmp; a2.lda = Hh;
+        GemmEpi e2; e2.out = gen_table; e2.out_f32 = 1; e2.ldc = Hh; e2.bias_n = al_b2;
+        launch_gemm<float>(s, a2, al_w2, Hh, 0, e2, V, Hh, Hh, 1);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipFree(tmp));
+    }
+    {   // pq_table[v] = post_quant_conv(normalize(codebook[v]))  (vq_model.py:284-299, :500-503)
+        launch_l2norm_rows(s, codebook, codebook_n, V, Dm);
+        float* tmp = nullptr;
+        HIPCHK(hipMalloc((void**)&tmp, (size_t)V * cfg.vq_z * 4));
+        GemmA a; a.ptr = codebook_n; a.lda = Dm;
+        GemmEpi e; e.out = tmp; e.out_f32 = 1; e.ldc = cfg.vq_z; e.bias_n = pq_b;
+        launch_gemm<float>(s, a, pq_w, Dm, 0, e, V, cfg.vq_z, Dm, 1);
+        if (bf) launch_convert<bf16>(s, tmp, 0, (bf16*)pq_table, (long)V * cfg.vq_z);
+        else launch_convert<float>(s, tmp, 0, (float*)pq_table, (long)V * cfg.vq_z);
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipFree(tmp));
+    }
+    {   // RoPE tables: inv_freq = theta^(-2j/128); cos/sin(pos * inv_freq) in fp32 (LlamaRotaryEmbedding)
+        std::vector<float> c((size_t)max_pos * 64), sn((size_t)max_pos * 64);
+        for (int j = 0; j < 64; ++j) {
+            const float inv = 1.0f / powf(cfg.rope_theta, (float)(2 * j) / 128.0f);
+            for (int p = 0; p < max_pos; ++p) {
+                const float f = (float)p * inv;
+                c[(size_t)p * 64 + j] = cosf(f); sn[(size_t)p * 64 + j] = sinf(f);
+            }
+        }
+        HIPCHK(hipMemcpy(cos_t, c.data(), c.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(sin_t, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipGetLastError());
+    finalized = true;
+    return PG_OK;
+}
+
+// =============================================================================== LLM
+// C = a . W^T into fp32 split-K slabs ``part`` [S_last][M][N].
+template <typename T>
+void pg_engine::gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, int K, bool allow_skinny) {
+    slab_last = (long)M * N;
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (allow_skinny && M <= 512 && K % 128 == 0) {
+            const int S = skinny_pick_splits(N, K);
+            if ((long)S * M * N <= part_elems) {
+                launch_gemm_skinny(s, a, W, part, M, N, K, S);
+                S_last = S;
+                return;
+            }
+        }
+    }
+    GemmA ga; ga.ptr = a; ga.lda = K;
+    GemmEpi e; e.out = part; e.out_f32 = 1; e.ldc = N;
+    launch_gemm<T>(s, ga, W, K, 0, e, M, N, K, 1);
+    S_last = 1;
+}
+
+// The layer stack on M token rows.  mode 0: decode (row m = batch row, slot len+n_dec);
+// mode 1: prefill (packed prompt tokens).  Residual stream x fp32 [M,H]; ends with the final
+// RMSNorm written to final_out (T).  Every GEMM leaves fp32 split-K slabs in ``part``; the
+// next elementwise kernel folds the reduction in (deterministic, no atomics).
+template <typename T>
+void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
+    const int Hh = H(), I = cfg.inter, HDm = HD();
+    const bool sk = mode == 0;
+    int S_pend = 0; long slab_pend = 0;
+    const float scale = 1.0f / sqrtf(128.0f);
+    for (int li = 0; li < cfg.n_layers; ++li) {
+        const Layer& ly = layers[li];
+        launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);
+        gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk);
+        launch_rope_kv<T>(s, part, S_last, slab_last, (T*)qbuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), mode, M,
+                          cfg.n_heads, slots, max_pos);
+        const bool timed = time_attn && mode == 0 && attn_ev_used + 2 <= attn_ev.size();
+        if (timed) (void)hipEventRecord(attn_ev[attn_ev_used], s);
+        launch_attn<T>(s, (const T*)qbuf, (T*)obuf, (const T*)kc(li), (const T*)vc(li), seq(), mode, M, cfg.n_heads, slots, scale);
+        if (timed) {
+            (void)hipEventRecord(attn_ev[attn_ev_used + 1], s);
+            double keys = 0;
+            for (int r = 0; r < R; ++r) keys += (double)(h_len[r] + n_dec_host + 1);
+            attn_ev_bytes.push_back(keys * cfg.n_heads * 128 * 2 * (double)esz);
+            attn_ev_used += 2;
+        }
+        gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk);
+        launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);
+        gemm_llm<T>(s, (const T*)xn, (const T*)ly.wgu, M, 2 * I, Hh, sk);
+        launch_silu_mul<T>(s, part, S_last, slab_last, (T*)hbuf, M, I);
+        gemm_llm<T>(s, (const T*)hbuf, (const T*)ly.wd, M, Hh, I, sk);
+        S_pend = S_last; slab_pend = slab_last;
+    }
+    launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps);
+}
+
+int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtype, const int32_t* pad_len, int R_, int L_,
+                       int pmode, void* hidden_out, int hidden_dtype, hipStream_t s) {
+    if (!finalized) FAIL(PG_ERR_STATE, "pg_finalize_weights not called");
+    if (R_ <= 0 || R_ > cfg.max_rows) FAIL(PG_ERR_CAPACITY, "rows %d > max_rows %d", R_, cfg.max_rows);
+    if (L_ + cfg.max_new + 1 > max_pos) FAIL(PG_ERR_CAPACITY, "padded length %d too long for the RoPE table (%d)", L_, max_pos);
+    if (!ids_dev && !emb_dev) FAIL(PG_ERR_ARG, "ids or embeds required");
+    HIPCHK(hipSetDevice(dev));
+    int ntok = 0;
+    h_len.assign(R_, 0);
+    int32_t* s_len = h_stage; int32_t* s_off = h_stage + cfg.max_rows; int32_t* s_last = h_stage + 2 * cfg.max_rows;
+    int32_t* s_row = h_stage + 4 * cfg.max_rows; int32_t* s_j = s_row + max_tok; int32_t* s_src = s_j + max_tok;
+    for (int r = 0; r < R_; ++r) {
+        const int pad = pad_len[r];
+        if (pad < 0 || pad >= L_) FAIL(PG_ERR_ARG, "row %d: pad_len %d not in [0,%d)", r, pad, L_);
+        const int len = L_ - pad;
+        if (len > cfg.max_prompt) FAIL(PG_ERR_CAPACITY, "row %d: %d prompt tokens > max_prompt %d", r, len, cfg.max_prompt);
+        h_len[r] = len; s_len[r] = len; s_off[r] = pmode == 0 ? pad : 0;
+        for (int j = 0; j < len; ++j) { s_row[ntok] = r; s_j[ntok] = j; s_src[ntok] = r * L_ + pad + j; ++ntok; }
+        s_last[r] = ntok - 1;
+    }
+    R = R_; L = L_; Ntok = ntok; pos_mode = pmode; n_dec_host = 0;
+    HIPCHK(hipEventRecord(ev_p0, s));
+    HIPCHK(hipMemcpyAsync(d_len, s_len, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_pos_off, s_off, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_last, s_last, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_tok_row, s_row, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_tok_j, s_j, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_tok_src, s_src, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_ndec, 0, 64, s));
+    // the pinned staging buffer is reused by the next call: wait for the copies
+    HIPCHK(hipStreamSynchronize(s));
+    if (ids_dev) launch_embed_gather(s, embed, ids_dev, d_tok_src, x, ntok, H(), cfg.vocab);
+    else launch_rows_to_f32(s, emb_dev, emb_dtype == PG_BF16, d_tok_src, x, ntok, H());
+    if (bf) run_layers<bf16>(s, ntok, 1, (bf16*)xn); else run_layers<float>(s, ntok, 1, (float*)xn);
+    // last real token of every row -> hfin (input of gen_head / lm_head for the first sample)
+    launch_copy_rows(s, xn, d_last, hfin, nullptr, R, (long)H() * esz);
+    if (hidden_out) {
+        const size_t ob = (size_t)R * L * H() * (hidden_dtype == PG_BF16 ? 2 : 4);
+        HIPCHK(hipMemsetAsync(hidden_out, 0, ob, s));
+        if (bf) launch_t_to_rows<bf16>(s, (const bf16*)xn, hidden_out, hidden_dtype == PG_BF16, d_tok_src, ntok, H());
+        else launch_t_to_rows<float>(s, (const float*)xn, hidden_out, hidden_dtype == PG_BF16, d_tok_src, ntok, H());
+    }
+    HIPCHK(hipEventRecord(ev_p1, s));
+    have_prefill_t = true;
+    HIPCHK(hipGetLastError());
+    prefilled = true;
+    return PG_OK;
+}
+
+// gen_head: Linear+b -> GELU(erf) -> Linear (second bias folded into the consumer)
+template <typename T>
+void pg_engine::head_logits(hipStream_t s, const T* in, int M) {
+    const int Hh = H(), G = cfg.gen_head_dim, V = cfg.img_vocab;
+    gemm_llm<T>(s, in, (const T*)gh_w1, M, G, Hh, true);
+    launch_bias_act<T>(s, part, S_last, slab_last, gh_b1, (T*)gh_mid, M, G, 1);
+    gemm_llm<T>(s, (const T*)gh_mid, (const T*)gh_w2, M, V, G, true);
+}
+
+void pg_engine::forward_decode(hipStream_t s) {
+    if (bf) run_layers<bf16>(s, R, 0, (bf16*)hfin); else run_layers<float>(s, R, 0, (float*)hfin);
+    launch_advance(s, d_ndec);
+}
+
+int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const int32_t* force_tok,
+                            const uint8_t* force_mask, int32_t* out_tok, float* logits_out, hipStream_t s) {
+    if (!prefilled) FAIL(PG_ERR_STATE, "pg_decode_image_tokens before pg_prefill");
+    if (R % 2) FAIL(PG_ERR_ARG, "CFG decode needs an even number of rows (got %d)", R);
+    if (n_dec_host != 0) FAIL(PG_ERR_STATE, "decode loop needs a fresh prefill");
+    if (T < 1 || T - 1 > cfg.max_new) FAIL(PG_ERR_CAPACITY, "T=%d exceeds max_new=%d", T, cfg.max_new);
+    HIPCHK(hipSetDevice(dev));
+    const int B = R / 2;
+    SampleArgs sa{};
+    sa.bias = gh_b2; sa.V = cfg.img_vocab; sa.cfg_weight = cfgw; sa.temperature = temp; sa.seed = seed;
+    sa.force_tok = force_tok; sa.force_mask = force_mask; sa.T = T; sa.out_tok = out_tok; sa.logits_out = logits_out;
+    sa.embed_table = gen_table; sa.x = x; sa.H = H(); sa.n_dec = d_ndec;
+    auto sample = [&](hipStream_t st) {
+        if (bf) head_logits<bf16>(st, (const bf16*)hfin, R); else head_logits<float>(st, (const float*)hfin, R);
+        sa.logits_partial = part; sa.S = S_last; sa.slab = slab_last;
+        launch_cfg_sample(st, sa, B);
+    };
+    if (time_attn) {
+        const size_t need = (size_t)2 * cfg.n_layers * T;
+        while (attn_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); attn_ev.push_back(e); }
+        attn_ev_used = 0; attn_ev_bytes.clear();
+    }
+    const bool graph = use_graph && !time_attn && T > 2;
+    hipStream_t ws = s;
+    if (graph) {      // graphs cannot be captured on the legacy default stream: hop to our own
+        HIPCHK(hipEventRecord(ev_in, s));
+        HIPCHK(hipStreamWaitEvent(istream, ev_in, 0));
+        ws = istream;
+    }
+    HIPCHK(hipEventRecord(ev_t0, ws));
+    // iteration i: sample token i from hfin (step index = n_dec), then run the stack on its
+    // embedding (appends KV slot len+n_dec) and advance n_dec.  The last iteration only samples.
+    sample(ws);
+    if (T > 1) { forward_decode(ws); n_dec_host++; }
+    int i = 1;
+    if (graph) {
+        std::vector<int64_t> key = {R, T, (int64_t)bf, (int64_t)__builtin_bit_cast(int32_t, cfgw),
+                                    (int64_t)__builtin_bit_cast(int32_t, temp), (int64_t)seed, (int64_t)force_tok,
+                                    (int64_t)force_mask, (int64_t)out_tok, (int64_t)logits_out};
+        if (!gexec || key != gkey) {
+            if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal));
+            sample(ws);
+            forward_decode(ws);
+            HIPCHK(hipStreamEndCapture(ws, &g));
+            HIPCHK(hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            gkey = key;
+        }
+        for (; i < T - 1; ++i) { HIPCHK(hipGraphLaunch(gexec, ws)); n_dec_host++; }
+    } else {
+        for (; i < T - 1; ++i) { sample(ws); forward_decode(ws); n_dec_host++; }
+    }
+    if (T > 1) sample(ws);
+    HIPCHK(hipEventRecord(ev_t1, ws));
+    if (graph) {
+        HIPCHK(hipEventRecord(ev_out, ws));
+        HIPCHK(hipStreamWaitEvent(s, ev_out, 0));
+    }
+    have_decode_t = true;
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_engine::step(const void* emb, int emb_dtype, void* hidden_out, int hidden_dtype, hipStream_t s) {
+    if (!prefilled) FAIL(PG_ERR_STATE, "pg_step before pg_prefill");
+    if (n_dec_host + 1 > cfg.max_new) FAIL(PG_ERR_CAPACITY, "decode capacity max_new=%d exhausted", cfg.max_new);
+    HIPCHK(hipSetDevice(dev));
+    launch_rows_to_f32(s, emb, emb_dtype == PG_BF16, nullptr, x, R, H());
+    forward_decode(s);
+    n_dec_host++;
+    if (hidden_out) {
+        if (bf) launch_t_to_rows<bf16>(s, (const bf16*)hfin, hidden_out, hidden_dtype == PG_BF16, nullptr, R, H());
+        else launch_t_to_rows<float>(s, (const float*)hfin, hidden_out, hidden_dtype == PG_BF16, nullptr, R, H());
+    }
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_engine::gen_head(const void* h_dev, int h_dtype, float* logits, int R_, hipStream_t s) {
+    if (!finalized) FAIL(PG_ERR_STATE, "pg_finalize_weights not called");
+    if (R_ < 1 || R_ > cfg.max_rows) FAIL(PG_ERR_CAPACITY, "rows %d > max_rows %d", R_, cfg.max_rows);
+    HIPCHK(hipSetDevice(dev));
+    // bring h into the compute dtype
+    if (bf) {
+        if (h_dtype == PG_BF16) HIPCHK(hipMemcpyAsync(gh_in, h_dev, (size_t)R_ * H() * 2, hipMemcpyDeviceToDevice, s));
+        else launch_t_to_rows<float>(s, (const float*)h_dev, gh_in, 1, nullptr, R_, H());
+        head_logits<bf16>(s, (const bf16*)gh_in, R_);
+    } else {
+        launch_rows_to_f32(s, h_dev, h_dtype == PG_BF16, nullptr, (float*)gh_in, R_, H());
+        head_logits<float>(s, (const float*)gh_in, R_);
+    }
+    launch_bias_f32(s, part, S_last, slab_last, gh_b2, logits, R_, cfg.img_vocab);
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int* out_len, hipStream_t s) {
+    if (!prefilled) FAIL(PG_ERR_STATE, "pg_generate_text_greedy before pg_prefill");
+    if (!cfg.with_lm_head) FAIL(PG_ERR_STATE, "engine created without lm_head");
+    if (n_dec_host != 0) FAIL(PG_ERR_STATE, "text decode needs a fresh prefill");
+    if (max_new < 1 || max_new > cfg.max_new || max_new > 1000) FAIL(PG_ERR_CAPACITY, "max_new=%d exceeds capacity %d", max_new, cfg.max_new);
+    HIPCHK(hipSetDevice(dev));
+    const int B = R;
+    std::vector<int32_t> ones(B, 1);
+    HIPCHK(hipMemcpyAsync(d_unf, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(d_anyunf, 0, 1024 * 4, s));
+    HIPCHK(hipStreamSynchronize(s));
+    TextArgs ta{};
+    ta.V = cfg.vocab; ta.eos = eos; ta.min_new = min_new; ta.out = out; ta.max_new = max_new; ta.unfinished = d_unf;
+    ta.any_unfinished = d_anyunf; ta.embed_table = embed; ta.x = x; ta.H = H(); ta.n_dec = d_ndec;
+    std::vector<int32_t> flags(1024);
+    int checked = 0, done_len = -1;
+    for (int step_i = 0; step_i < max_new; ++step_i) {
+        if (bf) gemm_llm<bf16>(s, (const bf16*)hfin, (const bf16*)lm_head, B, cfg.vocab, H(), true);
+        else gemm_llm<float>(s, (const float*)hfin, (const float*)lm_head, B, cfg.vocab, H(), true);
+        ta.logits_partial = part; ta.S = S_last; ta.slab = slab_last;
+        launch_text_argmax(s, ta, B);
+        const bool last = step_i == max_new - 1;
+        if (!last) { forward_decode(s); n_dec_host++; }
+        if (last || (step_i & 7) == 7) {
+            HIPCHK(hipMemcpyAsync(flags.data(), d_anyunf, 1024 * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (; checked <= step_i; ++checked)
+                if (flags[(checked + 1) & 1023] == 0) { done_len = checked + 1; break; }
+            if (done_len >= 0) break;
+        }
+    }
+    if (done_len < 0) done_len = max_new;
+    if (out_len) *out_len = done_len;
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
+// =============================================================================== VQ-16
+template <typename T>
+void pg_engine::gn(hipStream_t s, const NormW& n, const T* in, T* out, int B, int HW, int swish) {
+    launch_gn_stats(s, in, bf ? 1 : 0, gn_stats, gn_ws, B, HW, n.c, 1e-6f);
+    launch_gn_apply<T>(s, in, gn_stats, n.g, n.b, out, B, HW, n.c, swish);
+}
+template <typename T>
+void pg_engine::conv3(hipStream_t s, const ConvW& cw, const T* in, T* out, const T* residual, int B, int Hi, int Wi,
+                      int up, int stride2) {
+    GemmA a; a.kind = stride2 ? 2 : 1; a.ptr = in; a.Hi = Hi; a.Wi = Wi; a.Cin = cw.cin; a.up = up; a.zeros = zeros;
+    const int Ho = stride2 ? Hi / 2 : (Hi << up), Wo = stride2 ? Wi / 2 : (Wi << up);
+    GemmEpi e; e.out = out; e.out_f32 = 0; e.ldc = cw.cout; e.bias_n = cw.b; e.residual = residual;
+    launch_gemm<T>(s, a, (const T*)cw.w, 9L * cw.cin, 0, e, B * Ho * Wo, cw.cout, 9 * cw.cin, 1);
+}
+template <typename T>
+void pg_engine::conv1(hipStream_t s, const ConvW& cw, const T* in, T* out, const T* residual, long M) {
+    GemmA a; a.ptr = in; a.lda = cw.cin;
+    GemmEpi e; e.out = out; e.out_f32 = 0; e.ldc = cw.cout; e.bias_n = cw.b; e.residual = residual;
+    launch_gemm<T>(s, a, (const T*)cw.w, cw.cin, 0, e, (int)M, cw.cout, cw.cin, 1);
+}
+// ResnetBlock.forward (vq_model.py:337-352) on ``cur``; result becomes the new ``cur``.
+template <typename T>
+void pg_engine::resblock(hipStream_t s, const ResBlockW& r, int B, int Hs, int Ws) {
+    const int HW = Hs * Ws;
+    gn<T>(s, r.n1, (const T*)cur, (T*)t1, B, HW, 1);
+    conv3<T>(s, r.c1, (const T*)t1, (T*)t2, nullptr, B, Hs, Ws, 0, 0);
+    gn<T>(s, r.n2, (const T*)t2, (T*)t1, B, HW, 1);
+    const T* res = (const T*)cur;
+    if (r.has_nin) { conv1<T>(s, r.nin, (const T*)cur, (T*)t3, nullptr, (long)B * HW); res = (const T*)t3; }
+    conv3<T>(s, r.c2, (const T*)t1, (T*)t2, res, B, Hs, Ws, 0, 0);
+    std::swap(cur, t2);
+}
+// AttnBlock.forward (vq_model.py:366-390): single head over HW tokens, scale C^-0.5.
+template <typename T>
+void pg_engine::attnblock(hipStream_t s, const AttnW& a, int B, int HW) {
+    const int C = a.n.c;
+    gn<T>(s, a.n, (const T*)cur, (T*)t1, B, HW, 0);
+    conv1<T>(s, a.q, (const T*)t1, (T*)aq, nullptr, (long)B * HW);
+    conv1<T>(s, a.k, (const T*)t1, (T*)ak, nullptr, (long)B * HW);
+    {   // V^T[b] = Wv . t1[b]^T + bv  -> [C, HW]  (operands swapped so the PV GEMM sees K-contiguous V)
+        GemmA ga; ga.ptr = a.v.w; ga.lda = C; ga.strideA = 0;
+        GemmEpi e; e.out = avt; e.out_f32 = 0; e.ldc = HW; e.strideC = (long)C * HW; e.bias_m = a.v.b;
+        launch_gemm<T>(s, ga, (const T*)t1, C, (long)HW * C, e, C, HW, C, B);
+    }
+    {   // scores[b] = q[b] . k[b]^T   fp32 [HW, HW]
+        GemmA ga; ga.ptr = aq; ga.lda = C; ga.strideA = (long)HW * C;
+        GemmEpi e; e.out = ascore; e.out_f32 = 1; e.ldc = HW; e.strideC = (long)HW * HW;
+        launch_gemm<T>(s, ga, (const T*)ak, C, (long)HW * C, e, HW, HW, C, B);
+    }
+    launch_softmax_rows<T>(s, ascore, (T*)ap, B * HW, HW, 1.0f / sqrtf((float)C));
+    {   // o[b] = P[b] . V^T[b]^T  -> [HW, C]
+        GemmA ga; ga.ptr = ap; ga.lda = HW; ga.strideA = (long)HW * HW;
+        GemmEpi e; e.out = ao; e.out_f32 = 0; e.ldc = C; e.strideC = (long)HW * C;
+        launch_gemm<T>(s, ga, (const T*)avt, HW, (long)C * HW, e, HW, C, HW, B);
+    }
+    conv1<T>(s, a.p, (const T*)ao, (T*)t2, (const T*)cur, (long)B * HW);
+    std::swap(cur, t2);
+}
+
+// VQModel.decode_code (vq_model.py:505-508) -> Decoder.forward (:193-214).
+template <typename T>
+int pg_engine::vq_decode(const int32_t* codes, void* img_out, int out_dtype, int B, hipStream_t s) {
+    if (!finalized) FAIL(PG_ERR_STATE, "pg_finalize_weights not called");
+    if (B < 1 || B > cfg.max_images) FAIL(PG_ERR_CAPACITY, "images %d > max_images %d", B, cfg.max_images);
+    HIPCHK(hipSetDevice(dev));
+    HIPCHK(hipEventRecord(ev_v0, s));
+    cur = vbuf[0]; t1 = vbuf[1]; t2 = vbuf[2]; t3 = vbuf[3];
+    const int g = cfg.grid, nres = cfg.vq_levels;
+    launch_vq_gather<T>(s, (const T*)pq_table, codes, (T*)t1, B * g * g, cfg.vq_z, cfg.img_vocab);
+    conv3<T>(s, dec.conv_in, (const T*)t1, (T*)cur, nullptr, B, g, g, 0, 0);
+    resblock<T>(s, dec.mid0, B, g, g);
+    attnblock<T>(s, dec.mid1, B, g * g);
+    resblock<T>(s, dec.mid2, B, g, g);
+    int side = g;
+    for (int bi = 0; bi < nres; ++bi) {
+        const VqLevel& lv = dec.levels[bi];
+        for (size_t j = 0; j < lv.res.size(); ++j) {
+            resblock<T>(s, lv.res[j], B, side, side);
+            if (j < lv.attn.size()) attnblock<T>(s, lv.attn[j], B, side * side);
+        }
+        if (lv.has_resample) {   // Upsample.forward (:417-427): nearest 2x folded into the conv's addressing
+            conv3<T>(s, lv.resample, (const T*)cur, (T*)t2, nullptr, B, side, side, 1, 0);
+            std::swap(cur, t2);
+            side *= 2;
+        }
+    }
+    gn<T>(s, dec.norm_out, (const T*)cur, (T*)t1, B, side * side, 1);
+    launch_conv3x3_small<T>(s, (const T*)t1, (const T*)dec.conv_out.w, dec.conv_out.b, img_out, out_dtype == PG_BF16, B, side, side,
+                            dec.conv_out.cin, 3);
+    HIPCHK(hipEventRecord(ev_v1, s));
+    have_vq_t = true;
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
+// VQModel.encode (vq_model.py:494-498) -> Encoder.forward (:105-124) -> VectorQuantizer (:236-258).
+template <typename T>
+int pg_engine::vq_encode(const void* img, int img_dtype, int64_t* idx, int B, hipStream_t s) {
+    if (!finalized) FAIL(PG_ERR_STATE, "pg_finalize_weights not called");
+    if (!cfg.with_vq_encoder) FAIL(PG_ERR_STATE, "engine created without the VQ encoder");
+    if (B < 1 || B > cfg.max_images) FAIL(PG_ERR_CAPACITY, "images %d > max_images %d", B, cfg.max_images);
+    HIPCHK(hipSetDevice(dev));
+    cur = vbuf[0]; t1 = vbuf[1]; t2 = vbuf[2]; t3 = vbuf[3];
+    const int nres = cfg.vq_levels;
+    int side = img_size();
+    launch_conv3x3_in<T>(s, img, img_dtype == PG_BF16, enc_in_w, enc_in_b, (T*)cur, B, side, side, 3, cfg.vq_ch);
+    for (int lvl = 0; lvl < nres; ++lvl) {
+        const VqLevel& lv = enc.levels[lvl];
+        for (size_t j = 0; j < lv.res.size(); ++j) {
+            resblock<T>(s, lv.res[j], B, side, side);
+            if (j < lv.attn.size()) attnblock<T>(s, lv.attn[j], B, side * side);
+        }
+        if (lv.has_resample) {
+            conv3<T>(s, lv.resample, (const T*)cur, (T*)t2, nullptr, B, side, side, 0, 1);
+            std::swap(cur, t2);
+            side /= 2;
+        }
+    }
+    resblock<T>(s, enc.mid0, B, side, side);
+    attnblock<T>(s, enc.mid1, B, side * side);
+    resblock<T>(s, enc.mid2, B, side, side);
+    gn<T>(s, enc.norm_out, (const T*)cur, (T*)t1, B, side * side, 1);
+    conv3<T>(s, enc.conv_out, (const T*)t1, (T*)t2, nullptr, B, side, side, 0, 0);
+    {   // quant_conv 1x1 z -> img_dim, fp32 out
+        GemmA a; a.ptr = t2; a.lda = cfg.vq_z;
+        GemmEpi e; e.out = enc_z; e.out_f32 = 1; e.ldc = cfg.img_dim; e.bias_n = qc_b;
+        launch_gemm<T>(s, a, (const T*)qc_w, cfg.vq_z, 0, e, B * side * side, cfg.img_dim, cfg.vq_z, 1);
+    }
+    launch_vq_argmin(s, enc_z, codebook_n, idx, B * side * side, cfg.img_dim, cfg.img_vocab);
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
+int pg_engine::fetch_timing() {
+    if (have_decode_t) { HIPCHK(hipEventSynchronize(ev_t1)); HIPCHK(hipEventElapsedTime(&timing.decode_ms, ev_t0, ev_t1)); have_decode_t = false; }
+    if (have_prefill_t) { HIPCHK(hipEventSynchronize(ev_p1)); HIPCHK(hipEventElapsedTime(&timing.prefill_ms, ev_p0, ev_p1)); have_prefill_t = false; }
+    if (have_vq_t) { HIPCHK(hipEventSynchronize(ev_v1)); HIPCHK(hipEventElapsedTime(&timing.vq_ms, ev_v0, ev_v1)); have_vq_t = false; }
+    if (attn_ev_used) {
+        float sum = 0.f; double by = 0;
+        for (size_t i = 0; i + 1 < attn_ev_used; i += 2) {
+            float ms = 0.f;
+            HIPCHK(hipEventSynchronize(attn_ev[i + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, attn_ev[i], attn_ev[i + 1]));
+            sum += ms; by += attn_ev_bytes[i / 2];
+        }
+        timing.attn_ms_sum = sum; timing.attn_launches = (int)(attn_ev_used / 2); timing.attn_bytes_sum = by;
+        attn_ev_used = 0;
+    }
+    return PG_OK;
+}
+
+// =============================================================================== C ABI
+extern "C" {
+
+int pg_create(pg_handle* out, const pg_config* cfg, int device_id) {
+    if (!out || !cfg) { g_err = "pg_create: null argument"; return PG_ERR_ARG; }
+    pg_engine* e = new pg_engine();
+    e->cfg = *cfg; e->dev = device_id;
+    const int rc = e->create();
+    if (rc != PG_OK) { g_err = e->err; e->destroy(); delete e; *out = nullptr; return rc; }
+    *out = e;
+    return PG_OK;
+}
+int pg_destroy(pg_handle h) { if (h) { h->destroy(); delete h; } return PG_OK; }
+const char* pg_last_error(pg_handle h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int pg_load_tensor(pg_handle h, const char* name, const void* src, int dtype, const int64_t* shape, int ndim) {
+    if (!h || !name || !src) return PG_ERR_ARG;
+    return h->load_tensor(name, src, dtype, shape, ndim);
+}
+int pg_finalize_weights(pg_handle h, int* missing, pg_stream s) { return h ? h->finalize(missing, (hipStream_t)s) : PG_ERR_ARG; }
+
+int pg_prefill(pg_handle h, const int32_t* ids_dev, const int32_t* pad_len_host, int R, int L, int position_mode,
+               void* hidden_out_dev, int hidden_dtype, pg_stream s) {
+    if (!h || !ids_dev || !pad_len_host) return PG_ERR_ARG;
+    return h->prefill(ids_dev, nullptr, 0, pad_len_host, R, L, position_mode, hidden_out_dev, hidden_dtype, (hipStream_t)s);
+}
+int pg_prefill_embeds(pg_handle h, const void* embeds_dev, int embeds_dtype, const int32_t* pad_len_host, int R, int L,
+                      int position_mode, void* hidden_out_dev, int hidden_dtype, pg_stream s) {
+    if (!h || !embeds_dev || !pad_len_host) return PG_ERR_ARG;
+    return h->prefill(nullptr, embeds_dev, embeds_dtype, pad_len_host, R, L, position_mode, hidden_out_dev, hidden_dtype, (hipStream_t)s);
+}
+int pg_step(pg_handle h, const void* embeds_dev, int embeds_dtype, void* hidden_out_dev, int hidden_dtype, pg_stream s) {
+    if (!h || !embeds_dev) return PG_ERR_ARG;
+    return h->step(embeds_dev, embeds_dtype, hidden_out_dev, hidden_dtype, (hipStream_t)s);
+}
+int pg_gen_head(pg_handle h, const void* h_dev, int h_dtype, float* logits_dev, int R, pg_stream s) {
+    if (!h || !h_dev || !logits_dev) return PG_ERR_ARG;
+    return h->gen_head(h_dev, h_dtype, logits_dev, R, (hipStream_t)s);
+}
+int pg_gen_embed(pg_handle h, const int32_t* tok_dev, void* out_dev, int out_dtype, int R, pg_stream s) {
+    if (!h || !tok_dev || !out_dev) return PG_ERR_ARG;
+    if (!h->finalized) { h->err = "pg_finalize_weights not called"; return PG_ERR_STATE; }
+    (void)hipSetDevice(h->dev);
+    hipStream_t st = (hipStream_t)s;
+    if (out_dtype == PG_F32) launch_embed_gather(st, h->gen_table, tok_dev, nullptr, (float*)out_dev, R, h->H(), h->cfg.img_vocab);
+    else {
+        // gather fp32 rows into x-sized scratch is not safe mid-sequence: convert row by row through part
+        launch_embed_gather(st, h->gen_table, tok_dev, nullptr, h->part, R, h->H(), h->cfg.img_vocab);
+        launch_f32_to_rows(st, h->part, out_dev, 1, nullptr, R, h->H());
+    }
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
+int pg_embed_tokens(pg_handle h, const int32_t* ids_dev, void* out_dev, int out_dtype, int n, pg_stream s) {
+    if (!h || !ids_dev || !out_dev) return PG_ERR_ARG;
+    (void)hipSetDevice(h->dev);
+    hipStream_t st = (hipStream_t)s;
+    if (out_dtype == PG_F32) launch_embed_gather(st, h->embed, ids_dev, nullptr, (float*)out_dev, n, h->H(), h->cfg.vocab);
+    else {
+        if ((long)n * h->H() > h->part_elems) { h->err = "pg_embed_tokens: too many tokens for bf16 output scratch"; return PG_ERR_CAPACITY; }
+        launch_embed_gather(st, h->embed, ids_dev, nullptr, h->part, n, h->H(), h->cfg.vocab);
+        launch_f32_to_rows(st, h->part, out_dev, 1, nullptr, n, h->H());
+    }
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
+int pg_decode_image_tokens(pg_handle h, int T, float cfg_weight, float temperature, uint64_t seed,
+                           const int32_t* force_tok_dev, const uint8_t* force_mask_dev, int32_t* out_tok_dev,
+                           float* logits_out_dev, pg_stream s) {
+    if (!h || !out_tok_dev) return PG_ERR_ARG;
+    return h->decode_image(T, cfg_weight, temperature, seed, force_tok_dev, force_mask_dev, out_tok_dev, logits_out_dev, (hipStream_t)s);
+}
+int pg_generate_text_greedy(pg_handle h, int max_new, int min_new, int eos_id, int64_t* out_dev, int* out_len_host, pg_stream s) {
+    if (!h || !out_dev) return PG_ERR_ARG;
+    return h->text_greedy(max_new, min_new, eos_id, out_dev, out_len_host, (hipStream_t)s);
+}
+int pg_vq_decode(pg_handle h, const int32_t* codes_dev, void* img_out_dev, int out_dtype, int B, pg_stream s) {
+    if (!h || !codes_dev || !img_out_dev) return PG_ERR_ARG;
+    return h->bf ? h->vq_decode<bf16>(codes_dev, img_out_dev, out_dtype, B, (hipStream_t)s)
+                 : h->vq_decode<float>(codes_dev, img_out_dev, out_dtype, B, (hipStream_t)s);
+}
+int pg_vq_encode(pg_handle h, const void* img_dev, int img_dtype, int64_t* idx_out_dev, int B, pg_stream s) {
+    if (!h || !img_dev || !idx_out_dev) return PG_ERR_ARG;
+    return h->bf ? h->vq_encode<bf16>(img_dev, img_dtype, idx_out_dev, B, (hipStream_t)s)
+                 : h->vq_encode<float>(img_dev, img_dtype, idx_out_dev, B, (hipStream_t)s);
+}
+int pg_get_timing(pg_handle h, pg_timing* out) {
+    if (!h || !out) return PG_ERR_ARG;
+    const int rc = h->fetch_timing();
+    *out = h->timing;
+    return rc;
+}
+int pg_set_option(pg_handle h, const char* key, int64_t value) {
+    if (!h || !key) return PG_ERR_ARG;
+    if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
+    if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
+    h->err = std::string("unknown option ") + key;
+    return PG_ERR_ARG;
+}
+int64_t pg_device_bytes(pg_handle h) { return h ? h->bytes : 0; }
+
+int pg_debug_read(pg_handle h, const char* name, int index, void* dst_dev, int64_t max_bytes, pg_stream s) {
+    if (!h || !name || !dst_dev) return PG_ERR_ARG;
+    const void* src = nullptr; int64_t n = 0;
+    const std::string nm = name;
+    if (nm == "kcache") { src = h->kc(index); n = (int64_t)h->kv_layer_elems() * h->esz; }
+    else if (nm == "vcache") { src = h->vc(index); n = (int64_t)h->kv_layer_elems() * h->esz; }
+    else if (nm == "x") { src = h->x; n = (int64_t)h->max_tok * h->H() * 4; }
+    else if (nm == "xn") { src = h->xn; n = (int64_t)h->max_tok * h->H() * h->esz; }
+    else if (nm == "hfin") { src = h->hfin; n = (int64_t)h->cfg.max_rows * h->H() * h->esz; }
+    else if (nm == "gen_table") { src = h->gen_table; n = (int64_t)h->cfg.img_vocab * h->H() * 4; }
+    else if (nm == "pq_table") { src = h->pq_table; n = (int64_t)h->cfg.img_vocab * h->cfg.vq_z * h->esz; }
+    else if (nm == "qbuf") { src = h->qbuf; n = (int64_t)h->max_tok * h->HD() * h->esz; }
+    else if (nm == "obuf") { src = h->obuf; n = (int64_t)h->max_tok * h->HD() * h->esz; }
+    else { h->err = "pg_debug_read: unknown buffer " + nm; return PG_ERR_NAME; }
+    if (n > max_bytes) n = max_bytes;
+    (void)hipSetDevice(h->dev);
+    if (hipMemcpyAsync(dst_dev, src, (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) { h->err = "pg_debug_read: copy failed"; return PG_ERR_HIP; }
+    return PG_OK;
+}
+
+int pg_op_rmsnorm(pg_handle h, float* x_dev, const float* partial_dev, int S, const void* w_dev, void* out_dev, int M, int H,
+                  float eps, pg_stream s) {
+    if (!h || !x_dev || !w_dev) return PG_ERR_ARG;
+    (void)hipSetDevice(h->dev);
+    if (h->bf) launch_rmsnorm<bf16>((hipStream_t)s, x_dev, partial_dev, S, (long)M * H, (const bf16*)w_dev, (bf16*)out_dev, M, H, eps);
+    else launch_rmsnorm<float>((hipStream_t)s, x_dev, partial_dev, S, (long)M * H, (const float*)w_dev, (float*)out_dev, M, H, eps);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
+int pg_op_gemm(pg_handle h, const void* a_dev, const void* w_dev, float* out_dev, int M, int N, int K, int force_kind,
+               int* S_out, pg_stream s) {
+    if (!h || !a_dev || !w_dev || !out_dev) return PG_ERR_ARG;
+    (void)hipSetDevice(h->dev);
+    int S = 1;
+    if (h->bf && (force_kind == 1 || (force_kind == 0 && M <= 128)) && K % 128 == 0) {
+        S = skinny_pick_splits(N, K);
+        launch_gemm_skinny((hipStream_t)s, (const bf16*)a_dev, (const bf16*)w_dev, out_dev, M, N, K, S);
+    } else {
+        GemmA ga; ga.ptr = a_dev; ga.lda = K;
+        GemmEpi e; e.out = out_dev; e.out_f32 = 1; e.ldc = N;
+        if (h->bf) launch_gemm<bf16>((hipStream_t)s, ga, (const bf16*)w_dev, K, 0, e, M, N, K, 1);
+        else launch_gemm<float>((hipStream_t)s, ga, (const float*)w_dev, K, 0, e, M, N, K, 1);
+    }
+    if (S_out) *S_out = S;
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
+int pg_op_conv3x3(pg_handle h, const void* x_dev, const void* w_dev, const float* bias_dev, const void* residual_dev,
+                  void* out_dev, int B, int Hi, int Wi, int Cin, int Cout, int up, int stride2, pg_stream s) {
+    if (!h || !x_dev || !w_dev || !out_dev) return PG_ERR_ARG;
+    (void)hipSetDevice(h->dev);
+    ConvW cw; cw.w = (void*)w_dev; cw.b = (float*)bias_dev; cw.cin = Cin; cw.cout = Cout;
+    if (h->bf) h->conv3<bf16>((hipStream_t)s, cw, (const bf16*)x_dev, (bf16*)out_dev, (const bf16*)residual_dev, B, Hi, Wi, up, stride2);
+    else h->conv3<float>((hipStream_t)s, cw, (const float*)x_dev, (float*)out_dev, (const float*)residual_dev, B, Hi, Wi, up, stride2);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
+int pg_op_groupnorm(pg_handle h, const void* x_dev, const float* gamma_dev, const float* beta_dev, void* out_dev, int B,
+                    int HW, int C, int swish, pg_stream s) {
+    if (!h || !x_dev || !out_dev) return PG_ERR_ARG;
+    if (B > h->cfg.max_images) { h->err = "pg_op_groupnorm: B > max_images"; return PG_ERR_CAPACITY; }
+    (void)hipSetDevice(h->dev);
+    NormW n; n.g = (float*)gamma_dev; n.b = (float*)beta_dev; n.c = C;
+    if (h->bf) h->gn<bf16>((hipStream_t)s, n, (const bf16*)x_dev, (bf16*)out_dev, B, HW, swish);
+    else h->gn<float>((hipStream_t)s, n, (const float*)x_dev, (float*)out_dev, B, HW, swish);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,407 @@
+// GEMM kernels for gfx950:  C[M,N] = A[M,K] . W[N,K]^T  (both operands K-contiguous).
+//
+//  gemm_big   : bf16 MFMA (v_mfma_f32_16x16x32_bf16), 128x128x64 block tile, 4 waves (2x2,
+//               64x64 per wave = 4x4 MFMA tiles), operands staged HBM->LDS with
+//               global_load_lds_dwordx4 (no VGPR round trip), XOR-swizzled through the
+//               SOURCE address so ds_read_b128 fragment reads are bank-conflict free,
+//               double-buffered with one barrier per K tile.  A-operand loaders: plain
+//               row-major, or implicit im2col of a 3x3 conv over NHWC (optionally with the
+//               nearest-2x upsample folded into the address).  Used for prefill (MFMA-bound,
+//               M = packed prompt tokens) and the VQ-16 decoder convolutions.
+//  gemm_skinny: decode-step GEMM, M <= 128 rows: HBM-bound weight streaming.  Each wave streams
+//               its own 16 weight rows straight into VGPRs (64 contiguous bytes per lane per
+//               128-wide K chunk), the small x tile is shared through LDS, split-K over
+//               blockIdx.y fills the 256 CUs; fp32 partial slabs are reduced by the consumer
+//               kernel (deterministic, no atomics).
+//  gemm_f32   : plain fp32 tiled GEMM (PG_F32 parity mode); same loaders/epilogue.
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------- loaders
+template <typename T>
+struct PlainLoader {
+    const T* A; long lda; int M;
+    const T* rowp[4];
+    __device__ __forceinline__ void init(int i, int m) { rowp[i] = A + (long)(m < M ? m : M - 1) * lda; }
+    __device__ __forceinline__ void set_ktile(int) {}
+    __device__ __forceinline__ const T* ptr(int i, int k) const { return rowp[i] + k; }
+    __device__ __forceinline__ float elem(int m, int k) const { return m < M ? ET<T>::ld(A + (long)m * lda + k) : 0.f; }
+};
+
+// 3x3 conv, pad 1 (stride 1, optional nearest-2x upsample of the input) or the encoder's
+// stride-2 / pad (0,1,0,1) form.  Input NHWC [B,Hi,Wi,Cin]; output pixel m = (b, y, x)
+// over [B,Ho,Wo]; K index = tap*Cin + ci.
+template <typename T>
+struct ConvLoader {
+    const T* X; const T* zeros; int Hi, Wi, Cin, up, stride2, Ho, Wo, M;
+    const T* img[4]; int yy[4], xx[4];
+    int dy, dx, ci0;
+    __device__ __forceinline__ void decode(int m, int& b, int& y, int& x) const {
+        x = m % Wo; int t = m / Wo; y = t % Ho; b = t / Ho;
+    }
+    __device__ __forceinline__ void init(int i, int m) {
+        if (m >= M) m = M - 1;
+        int b, y, x; decode(m, b, y, x);
+        img[i] = X + (long)b * Hi * Wi * Cin; yy[i] = y; xx[i] = x;
+    }
+    __device__ __forceinline__ void set_ktile(int k0) {
+        const int tap = k0 / Cin; ci0 = k0 - tap * Cin; dy = tap / 3; dx = tap - dy * 3;
+    }
+    __device__ __forceinline__ bool src_yx(int y, int x, int ddy, int ddx, int& sy, int& sx) const {
+        if (stride2) { sy = 2 * y + ddy; sx = 2 * x + ddx; return sy < Hi && sx < Wi; }
+        const int oy = y + ddy - 1, ox = x + ddx - 1;
+        sy = oy >> up; sx = ox >> up;
+        return oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+    }
+    // k = k-tile base + chunk offset (chunk of 8 elements inside one tap because Cin % 64 == 0)
+    __device__ __forceinline__ const T* ptr(int i, int k) const {
+        int sy, sx; const int koff = k & 63;
+        if (!src_yx(yy[i], xx[i], dy, dx, sy, sx)) return zeros + koff;
+        return img[i] + ((long)sy * Wi + sx) * Cin + ci0 + koff;
+    }
+    __device__ __forceinline__ float elem(int m, int k) const {
+        if (m >= M) return 0.f;
+        int b, y, x; decode(m, b, y, x);
+        const int tap = k / Cin, ci = k - tap * Cin, ddy = tap / 3, ddx = tap - ddy * 3;
+        int sy, sx;
+        if (!src_yx(y, x, ddy, ddx, sy, sx)) return 0.f;
+        return ET<T>::ld(X + (((long)b * Hi + sy) * Wi + sx) * Cin + ci);
+    }
+};
+
+// ------------------------------------------------------------------------------- epilogue
+template <typename T>
+struct Epi {
+    GemmEpi e; int M, N;
+    __device__ __forceinline__ void operator()(int batch, int row, int col, float v) const {
+        if (row >= M || col >= N) return;
+        v *= e.scale;
+        if (e.bias_n) v += e.bias_n[col];
+        if (e.bias_m) v += e.bias_m[row];
+        if (e.residual) {
+            const long ldr = e.ldr ? e.ldr : e.ldc;
+            v += ET<T>::ld((const T*)e.residual + (long)batch * e.strideR + (long)row * ldr + col);
+        }
+        if (e.act == 1) v = gelu_erf(v);
+        const long o = (long)batch * e.strideC + (long)row * e.ldc + col;
+        if (e.out_f32) ((float*)e.out)[o] = v; else ET<T>::st((T*)e.out + o, v);
+    }
+};
+
+// ------------------------------------------------------------------------------- big MFMA GEMM
+#define BIG_BM 128
+#define BIG_BN 128
+#define BIG_BK 64
+#define BIG_TILE_BYTES (128 * 64 * 2)   // 16 KiB per operand tile
+#define BIG_LDS (4 * BIG_TILE_BYTES)    // A[2] + B[2]
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane*16 (hardware); source address is per lane.
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <class AL, class EP>
+__global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __restrict__ W, long ldb,
+                                                         long strideA, long strideB, EP ep, int M, int N,
+                                                         int K, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int batch = blockIdx.y;
+    // XCD-aware tile order: each XCD (blockIdx % 8) owns a contiguous run of tiles; inside
+    // the run tiles are grouped 8(M) x 8(N) so concurrently resident blocks share A and W panels in L2.
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    int tile_m, tile_n;
+    if (((ntm | ntn) & 7) == 0) {
+        const int sup = t >> 6, in = t & 63, gm = ntm >> 3;
+        tile_m = (sup % gm) * 8 + (in & 7);
+        tile_n = (sup / gm) * 8 + (in >> 3);
+    } else { tile_m = t % ntm; tile_n = t / ntm; }
+    const int m0 = tile_m * BIG_BM, n0 = tile_n * BIG_BN;
+
+    al.A_offset(strideA * batch);
+    const bf16* Wb = W + strideB * batch;
+    // staging assignment: wave w, instruction i covers tile rows (w*4+i)*8 .. +7, lane -> (row l>>3, chunk l&7)
+    const bf16* wrow[4]; int sc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (w * 4 + i) * 8 + (l >> 3);
+        sc[i] = ((l & 7) ^ ((r >> 1) & 7)) * 8;          // swizzled SOURCE chunk (elements)
+        al.init(i, m0 + r);
+        const int n = n0 + r;
+        wrow[i] = Wb + (long)(n < N ? n : N - 1) * ldb;
+    }
+    char* sA = smem; char* sB = smem + 2 * BIG_TILE_BYTES;
+    const int wbase = __builtin_amdgcn_readfirstlane(w) * 4 * 1024;
+
+    auto stage = [&](int buf, int kt) {
+        const int k0 = kt * BIG_BK;
+        al.set_ktile(k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(al.ptr(i, k0 + sc[i]), sA + buf * BIG_TILE_BYTES + wbase + i * 1024);
+            glds16(wrow[i] + k0 + sc[i], sB + buf * BIG_TILE_BYTES + wbase + i * 1024);
+        }
+    };
+
+    const int wm = w >> 1, wn = w & 1, g = l >> 4, lr = l & 15;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BIG_BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* a_t = sA + cur * BIG_TILE_BYTES;
+        const char* b_t = sB + cur * BIG_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wm * 64 + mt * 16 + lr;
+                af[mt] = *(const bf16x8*)(a_t + row * 128 + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int row = wn * 64 + nt * 16 + lr;
+                bfr[nt] = *(const bf16x8*)(b_t + row * 128 + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    // C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ep(batch, m0 + wm * 64 + mt * 16 + g * 4 + r, n0 + wn * 64 + nt * 16 + lr, acc[mt][nt][r]);
+}
+
+// loaders need a batch offset hook
+template <typename T> struct PlainLoaderB : PlainLoader<T> {
+    __device__ __forceinline__ void A_offset(long off) { this->A += off; }
+};
+template <typename T> struct ConvLoaderB : ConvLoader<T> {
+    __device__ __forceinline__ void A_offset(long off) { this->X += off; }
+};
+
+// ------------------------------------------------------------------------------- fp32 GEMM
+template <class AL, class EP>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(AL al, const float* __restrict__ W, long ldb,
+                                                      long strideA, long strideB, EP ep, int M, int N, int K) {
+    __shared__ float As[16][68];
+    __shared__ float Bs[16][68];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int batch = blockIdx.z;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    al.A_offset(strideA * batch);
+    const float* Wb = W + strideB * batch;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + j * 256, r = e >> 4, kk = e & 15;   // r in [0,64), kk in [0,16)
+            As[kk][r] = (k0 + kk < K) ? al.elem(m0 + r, k0 + kk) : 0.f;
+            const int n = n0 + r;
+            Bs[kk][r] = (n < N && k0 + kk < K) ? Wb[(long)n * ldb + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ep(batch, m0 + ty * 4 + i, n0 + tx * 4 + j, acc[i][j]);
+}
+
+// ------------------------------------------------------------------------------- launchers
+template <typename T> struct BigDispatch;
+
+template <> struct BigDispatch<bf16> {
+    static void run(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e,
+                    int M, int N, int K, int batch) {
+        Epi<bf16> ep{e, M, N};
+        const int ntm = (M + BIG_BM - 1) / BIG_BM, ntn = (N + BIG_BN - 1) / BIG_BN;
+        dim3 grid(ntm * ntn, batch), block(256);
+        if (a.kind == 0) {
+            PlainLoaderB<bf16> al; al.A = (const bf16*)a.ptr; al.lda = a.lda; al.M = M;
+            auto kfn = gemm_big_kernel<PlainLoaderB<bf16>, Epi<bf16>>;
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS); attr = true; }
+            hipLaunchKernelGGL(kfn, grid, block, BIG_LDS, s, al, W, ldb, a.strideA, strideB, ep, M, N, K, ntm, ntn);
+        } else {
+            ConvLoaderB<bf16> al; al.X = (const bf16*)a.ptr; al.zeros = (const bf16*)a.zeros;
+            al.Hi = a.Hi; al.Wi = a.Wi; al.Cin = a.Cin; al.up = a.up; al.stride2 = (a.kind == 2);
+            al.Ho = al.stride2 ? a.Hi / 2 : (a.Hi << a.up); al.Wo = al.stride2 ? a.Wi / 2 : (a.Wi << a.up); al.M = M;
+            auto kfn = gemm_big_kernel<ConvLoaderB<bf16>, Epi<bf16>>;
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS); attr = true; }
+            hipLaunchKernelGGL(kfn, grid, block, BIG_LDS, s, al, W, ldb, a.strideA, strideB, ep, M, N, K, ntm, ntn);
+        }
+    }
+};
+
+template <> struct BigDispatch<float> {
+    static void run(hipStream_t s, const GemmA& a, const float* W, long ldb, long strideB, const GemmEpi& e,
+                    int M, int N, int K, int batch) {
+        Epi<float> ep{e, M, N};
+        dim3 grid((N + 63) / 64, (M + 63) / 64, batch), block(256);
+        if (a.kind == 0) {
+            PlainLoaderB<float> al; al.A = (const float*)a.ptr; al.lda = a.lda; al.M = M;
+            hipLaunchKernelGGL((gemm_f32_kernel<PlainLoaderB<float>, Epi<float>>), grid, block, 0, s, al, W, ldb,
+                               a.strideA, strideB, ep, M, N, K);
+        } else {
+            ConvLoaderB<float> al; al.X = (const float*)a.ptr; al.zeros = (const float*)a.zeros;
+            al.Hi = a.Hi; al.Wi = a.Wi; al.Cin = a.Cin; al.up = a.up; al.stride2 = (a.kind == 2);
+            al.Ho = al.stride2 ? a.Hi / 2 : (a.Hi << a.up); al.Wo = al.stride2 ? a.Wi / 2 : (a.Wi << a.up); al.M = M;
+            hipLaunchKernelGGL((gemm_f32_kernel<ConvLoaderB<float>, Epi<float>>), grid, block, 0, s, al, W, ldb,
+                               a.strideA, strideB, ep, M, N, K);
+        }
+    }
+};
+
+template <typename T>
+void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strideB, const GemmEpi& e,
+                 int M, int N, int K, int batch) {
+    if (M <= 0 || N <= 0) return;
+    BigDispatch<T>::run(s, a, W, ldb, strideB, e, M, N, K, batch);
+}
+template void launch_gemm<float>(hipStream_t, const GemmA&, const float*, long, long, const GemmEpi&, int, int, int, int);
+template void launch_gemm<bf16>(hipStream_t, const GemmA&, const bf16*, long, long, const GemmEpi&, int, int, int, int);
+
+// ------------------------------------------------------------------------------- skinny GEMM
+#define SK_BK 128
+#define SK_ROWB 272           // LDS row stride (256 B of k + 16 B pad: conflict-free ds_read_b128)
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+                                                         float* __restrict__ out, int M, int N, int K, int nck) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 * MT*16*SK_ROWB
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
+    const int split = blockIdx.y, mblk = blockIdx.z;
+    const int mbase = mblk * 128;
+    const int n = blockIdx.x * 64 + w * 16 + lr;
+    const bf16* wp = W + (long)(n < N ? n : N - 1) * K + g * 32;
+    const int kbeg = split * nck * SK_BK;
+    constexpr int XB = MT * 16 * SK_ROWB;
+
+    u32x4 xs[MT];                     // staging registers for the x tile: MT x 16 B per thread
+    auto xload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + j * 256, row = v >> 4, cv = v & 15;
+            const int m = mbase + row;
+            if (m < M) xs[j] = *(const u32x4*)(x + (long)m * K + k0 + cv * 8);
+            else xs[j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto xstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + j * 256, row = v >> 4, cv = v & 15;
+            *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
+        }
+    };
+    bf16x8 wc[4], wn[4];
+    auto wload = [&](bf16x8* dst, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(wp + k0 + i * 8);
+    };
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    wload(wc, kbeg);
+    xload(kbeg);
+    xstore(0);
+    __syncthreads();
+    for (int c = 0; c < nck; ++c) {
+        const int knext = kbeg + (c + 1) * SK_BK;
+        const bool more = c + 1 < nck;
+        if (more) { wload(wn, knext); xload(knext); }
+        const char* xt = smem + (c & 1) * XB;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const char* rp = xt + (mt * 16 + lr) * SK_ROWB + g * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 a = *(const bf16x8*)(rp + i * 16);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wc[i], acc[mt], 0, 0, 0);
+            }
+        }
+        if (more) {
+            xstore((c + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wc[i] = wn[i];
+        }
+        __syncthreads();
+    }
+    if (n < N) {
+        float* o = out + (long)split * M * N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mbase + mt * 16 + g * 4 + r;
+                if (m < M) o[(long)m * N + n] = acc[mt][r];
+            }
+    }
+}
+
+int skinny_pick_splits(int N, int K) {
+    const int nblk = (N + 63) / 64, nchunks = K / SK_BK;
+    int best = 1;
+    for (int S = 1; S <= nchunks; ++S) {
+        if (nchunks % S) continue;
+        best = S;
+        if (nblk * S >= 256) break;
+    }
+    return best;
+}
+
+void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+    if (M <= 0) return;
+    const int nck = K / SK_BK / S;
+    const int mblocks = (M + 127) / 128;
+    const int mrows = M < 128 ? M : 128;
+    dim3 grid((N + 63) / 64, S, mblocks), block(256);
+    if (mrows <= 16) {
+        hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, block, 2 * 1 * 16 * SK_ROWB, s, x, W, out, M, N, K, nck);
+    } else if (mrows <= 32) {
+        hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, block, 2 * 2 * 16 * SK_ROWB, s, x, W, out, M, N, K, nck);
+    } else if (mrows <= 64) {
+        hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, block, 2 * 4 * 16 * SK_ROWB, s, x, W, out, M, N, K, nck);
+    } else {
+        auto kfn = gemm_skinny_kernel<8>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * SK_ROWB); attr = true; }
+        hipLaunchKernelGGL(kfn, grid, block, 2 * 8 * 16 * SK_ROWB, s, x, W, out, M, N, K, nck);
+    }
+}

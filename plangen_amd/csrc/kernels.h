@@ -1,0 +1,149 @@
+// Host-side launcher declarations for the HIP kernels (internal; the public surface is
+// include/plangen_hip.h).  T = float (PG_F32) or bf16 (PG_BF16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+// ---------------------------------------------------------------- GEMM  C = A . W^T
+// A operand description.  kind 0: row-major [M,K] with leading dim lda.
+// kind 1: implicit im2col of a 3x3 / pad 1 convolution over an NHWC tensor
+//         [B, Hi, Wi, Cin] (optionally nearest-2x upsampled on the fly: up=1), M = B*Ho*Wo,
+//         K = 9*Cin ordered (tap, ci); Cin % 64 == 0.
+// kind 2: same with stride 2 and the reference's asymmetric (0,1,0,1) padding
+//         (Downsample, vq_model.py:440-447): Ho = Hi/2.
+struct GemmA {
+    int kind = 0;
+    const void* ptr = nullptr;
+    long lda = 0, strideA = 0;          // strideA: per-batch (blockIdx.y) element stride
+    int Hi = 0, Wi = 0, Cin = 0, up = 0;
+    const void* zeros = nullptr;        // >= 256 B of zeros (conv halo source)
+};
+// Epilogue: v = acc*scale + bias_n[col] + bias_m[row] + residual[row,col]; act; store.
+struct GemmEpi {
+    void* out = nullptr;
+    int out_f32 = 1;                    // 1: float* out, 0: T* out
+    long ldc = 0, strideC = 0;
+    const float* bias_n = nullptr;
+    const float* bias_m = nullptr;
+    const void* residual = nullptr;     // T, same ldc/stride layout as out unless ldr set
+    long ldr = 0, strideR = 0;
+    float scale = 1.f;
+    int act = 0;                        // 0 none, 1 gelu(erf)
+};
+template <typename T>
+void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strideB,
+                 const GemmEpi& e, int M, int N, int K, int batch);
+
+// Skinny weight-streaming GEMM (decode): x [M,K] bf16 (M <= 128 per launch block-row),
+// W [N,K] bf16, out fp32 [S,M,N] split-K partial slabs (consumer kernels reduce over S).
+// Returns S.  N % 16 == 0, K % 128 == 0.
+int skinny_pick_splits(int N, int K);
+void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
+
+// ---------------------------------------------------------------- LLM elementwise / attention
+// x (fp32 residual stream, in/out) += sum_s partial[s];  xn = w * (x * rsqrt(mean(x^2)+eps)).
+// partial may be null (S=0).  xn may be null (residual update only).
+template <typename T>
+void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
+                    int M, int H, float eps);
+// gather rows: dst fp32 [n,H] = table[ids[idx]]  (table fp32)
+void launch_embed_gather(hipStream_t s, const float* table, const int32_t* ids, const int32_t* src_idx, float* dst,
+                         int n, int H, int vocab);
+// byte-row copy with optional gather (src_idx) / scatter (dst_idx)
+void launch_copy_rows(hipStream_t s, const void* src, const int32_t* src_idx, void* dst, const int32_t* dst_idx,
+                      int n, long row_bytes);
+// src (any of f32/bf16) rows -> fp32 dst with optional row index list (src_row[i] or i)
+void launch_rows_to_f32(hipStream_t s, const void* src, int src_bf16, const int32_t* src_row, float* dst, int n, int H);
+void launch_f32_to_rows(hipStream_t s, const float* src, void* dst, int dst_bf16, const int32_t* dst_row, int n, int H);
+template <typename T>
+void launch_t_to_rows(hipStream_t s, const T* src, void* dst, int dst_bf16, const int32_t* dst_row, int n, int H);
+
+struct SeqState {              // device arrays describing the rows of the current batch
+    const int32_t* len;        // [R] real prompt tokens of row r (KV slots filled by prefill)
+    const int32_t* pos_off;    // [R] RoPE position of slot 0 (pad_len in position_mode 0, 0 in mode 1)
+    const int32_t* n_dec;      // [1] decode steps completed so far
+    const int32_t* tok_row;    // [Ntok] prefill: row of packed token t
+    const int32_t* tok_j;      // [Ntok] prefill: slot of packed token t
+};
+// qkv partial fp32 [S, M, 3*nh*128] -> RoPE(q), RoPE(k); q -> qbuf T [M, nh*128];
+// k,v -> caches [R][nh][slots][128].  mode 0: decode (token m = row m, slot = len+n_dec);
+// mode 1: prefill (token m -> tok_row/tok_j).
+template <typename T>
+void launch_rope_kv(hipStream_t s, const float* qkv, int S, long slab, T* qbuf, T* kc, T* vc,
+                    const float* cos_t, const float* sin_t, SeqState st, int mode, int M, int nh,
+                    int slots, int max_pos);
+// softmax(q.K^T * scale) V per (query, head).  mode as above: decode klen = len+n_dec+1;
+// prefill klen = tok_j+1.
+template <typename T>
+void launch_attn(hipStream_t s, const T* qbuf, T* obuf, const T* kc, const T* vc, SeqState st, int mode,
+                 int M, int nh, int slots, float scale);
+// h = silu(g) * u from gate-up partial fp32 [S, M, 2I] whose columns are interleaved in
+// blocks of 16 (16 gate, 16 up, ...)
+template <typename T>
+void launch_silu_mul(hipStream_t s, const float* gu, int S, long slab, T* h, int M, int I);
+// out T [M,N] = act(sum_s partial + bias)
+template <typename T>
+void launch_bias_act(hipStream_t s, const float* partial, int S, long slab, const float* bias, T* out,
+                     int M, int N, int act);
+// logits fp32 [M,N] = sum_s partial + bias
+void launch_bias_f32(hipStream_t s, const float* partial, int S, long slab, const float* bias, float* out, int M, int N);
+
+struct SampleArgs {
+    const float* logits_partial; int S; long slab; const float* bias; int V;
+    float cfg_weight, temperature; uint64_t seed;
+    const int32_t* force_tok; const uint8_t* force_mask; int T;   // [B,T]
+    int32_t* out_tok;                                             // [B,T]
+    float* logits_out;                                            // [T,B,V] or null
+    const float* embed_table;                                     // [V, H] fp32 (gen_embed->gen_aligner)
+    float* x; int H;                                              // residual stream rows [2B, H]
+    const int32_t* n_dec;
+};
+void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B);
+// greedy text: argmax over vocab of (sum_s partial) per row + EOS bookkeeping, writes
+// out[b, step] (int64) and next-token embedding into x.
+struct TextArgs {
+    const float* logits_partial; int S; long slab; int V; int eos; int min_new;
+    int64_t* out; int max_new; int32_t* unfinished; int32_t* any_unfinished;
+    const float* embed_table; float* x; int H; const int32_t* n_dec;
+};
+void launch_text_argmax(hipStream_t s, const TextArgs& a, int B);
+void launch_advance(hipStream_t s, int32_t* n_dec);
+
+// ---------------------------------------------------------------- VQ
+// NHWC activations of type T.
+template <typename T>
+void launch_vq_gather(hipStream_t s, const T* table, const int32_t* codes, T* out, int n, int C, int vocab);
+// GroupNorm(32, eps) statistics: stats fp32 [B,32,2] = (mean, rstd); ws fp32 scratch >= B*32*2*nsplit
+void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, float* ws, int B, int HW, int C, float eps);
+// y = gn(x)*gamma+beta, optional swish
+template <typename T>
+void launch_gn_apply(hipStream_t s, const T* x, const float* stats, const float* gamma, const float* beta,
+                     T* y, int B, int HW, int C, int swish);
+// softmax over rows of fp32 [rows, n] * scale -> T
+template <typename T>
+void launch_softmax_rows(hipStream_t s, const float* x, T* y, int rows, int n, float scale);
+// 3x3 conv with tiny Cout (conv_out 128->3): NHWC T in -> NCHW out (fp32 or bf16)
+template <typename T>
+void launch_conv3x3_small(hipStream_t s, const T* x, const T* w /*[Cout][9][Cin]*/, const float* bias,
+                          void* out, int out_bf16, int B, int H, int W, int Cin, int Cout);
+// 3x3 conv with tiny Cin (encoder conv_in 3->128): NCHW in (f32/bf16) -> NHWC T
+template <typename T>
+void launch_conv3x3_in(hipStream_t s, const void* x, int x_bf16, const float* w /*[Cout][Cin][3][3]*/,
+                       const float* bias, T* out, int B, int H, int W, int Cin, int Cout);
+// nearest-code argmin: z fp32 [n, D] (D<=8) vs L2-normalised codebook fp32 [V, D] -> int64 idx
+void launch_vq_argmin(hipStream_t s, const float* z, const float* codebook, int64_t* idx, int n, int D, int V);
+
+// ---------------------------------------------------------------- weight conversion
+// dst (T) [rows, cols] at row offset <- src fp32/bf16 [rows, cols] (device staging)
+template <typename T>
+void launch_convert(hipStream_t s, const void* src, int src_bf16, T* dst, long n);
+// conv weight [Cout][Cin][kh][kw] -> [Cout][kh*kw][Cin]
+template <typename T>
+void launch_convert_conv(hipStream_t s, const void* src, int src_bf16, T* dst, int Cout, int Cin, int kk);
+// gate/up rows interleaved in blocks of 16: src [I,H] -> dst rows (n/16)*32 + which*16 + n%16
+template <typename T>
+void launch_convert_interleave16(hipStream_t s, const void* src, int src_bf16, T* dst, int I, int H, int which);
+void launch_to_f32(hipStream_t s, const void* src, int src_bf16, float* dst, long n);
+void launch_l2norm_rows(hipStream_t s, const float* src, float* dst, int n, int D);
+void launch_fill_zero(hipStream_t s, void* p, long bytes);

@@ -1,0 +1,480 @@
+// Language-model side kernels (HBM-bound, wave64): fused split-K-reduce + residual + RMSNorm,
+// RoPE + KV append, decode attention with per-lane-group online softmax, SwiGLU gate,
+// gen_head activation, fused CFG-mix + argmax / Gumbel-max sampling + next-embedding gather.
+// References: SURVEY.md K1-K9, a6.1-a6.4, a7-a9 (third-party transformers Llama formulas).
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------- RMSNorm
+// One 256-thread block per row.  x += sum_s partial[s]; xn = w * (x * rsqrt(mean(x^2)+eps)).
+// LlamaRMSNorm: stats in fp32, normalised value cast to the input dtype (fp32 residual
+// stream here) before the weight multiply; the product is rounded once to T.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ partial,
+                                                     int S, long slab, const T* __restrict__ w,
+                                                     T* __restrict__ xn, int H, float eps) {
+    __shared__ float red[4];
+    extern __shared__ float rowbuf[];           // H floats
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float* xr = x + (long)m * H;
+    float ss = 0.f;
+    for (int i = tid * 4; i < H; i += 1024) {
+        f32x4 v = *(const f32x4*)(xr + i);
+        for (int s = 0; s < S; ++s) {
+            const f32x4 p = *(const f32x4*)(partial + (long)s * slab + (long)m * H + i);
+            v += p;
+        }
+        if (S > 0) *(f32x4*)(xr + i) = v;
+        *(f32x4*)(rowbuf + i) = v;
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = block_sum<4>(ss, red);
+    if (!xn) return;
+    const float rstd = rsqrtf(ss / (float)H + eps);
+    for (int i = tid * 4; i < H; i += 1024) {
+        const f32x4 v = *(const f32x4*)(rowbuf + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            ET<T>::st(xn + (long)m * H + i + j, ET<T>::ld(w + i + j) * (v[j] * rstd));
+    }
+}
+template <typename T>
+void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
+                    int M, int H, float eps) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3(M), dim3(256), H * sizeof(float), s, x, partial, S, slab, w, xn, H, eps);
+}
+template void launch_rmsnorm<float>(hipStream_t, float*, const float*, int, long, const float*, float*, int, int, float);
+template void launch_rmsnorm<bf16>(hipStream_t, float*, const float*, int, long, const bf16*, bf16*, int, int, float);
+
+// ------------------------------------------------------------------------------- row movers
+// dst[t] = table[ids[src_idx ? src_idx[t] : t]]   (K1; packed left-pad-free gather)
+__global__ void embed_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                    const int32_t* __restrict__ src_idx, float* __restrict__ dst, int H, int vocab) {
+    const int t = blockIdx.x;
+    int id = ids[src_idx ? src_idx[t] : t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const float* src = table + (long)id * H;
+    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4)
+        *(f32x4*)(dst + (long)t * H + i) = *(const f32x4*)(src + i);
+}
+void launch_embed_gather(hipStream_t s, const float* table, const int32_t* ids, const int32_t* src_idx, float* dst,
+                         int n, int H, int vocab) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(n), dim3(256), 0, s, table, ids, src_idx, dst, H, vocab);
+}
+// byte-row copy with optional gather (src_idx) / scatter (dst_idx); row_bytes % 4 == 0
+__global__ void copy_rows_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ src_idx,
+                                 uint32_t* __restrict__ dst, const int32_t* __restrict__ dst_idx, int row_words) {
+    const int t = blockIdx.x;
+    const long rs = src_idx ? src_idx[t] : t, rd = dst_idx ? dst_idx[t] : t;
+    for (int i = threadIdx.x; i < row_words; i += blockDim.x) dst[rd * row_words + i] = src[rs * row_words + i];
+}
+void launch_copy_rows(hipStream_t s, const void* src, const int32_t* src_idx, void* dst, const int32_t* dst_idx,
+                      int n, long row_bytes) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(n), dim3(256), 0, s, (const uint32_t*)src, src_idx, (uint32_t*)dst, dst_idx, (int)(row_bytes / 4));
+}
+
+__global__ void rows_to_f32_kernel(const void* __restrict__ src, int src_bf16, const int32_t* __restrict__ src_row,
+                                   float* __restrict__ dst, int H) {
+    const int t = blockIdx.x;
+    const long r = src_row ? src_row[t] : t;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        float v = src_bf16 ? ET<bf16>::ld((const bf16*)src + r * H + i) : ((const float*)src)[r * H + i];
+        dst[(long)t * H + i] = v;
+    }
+}
+void launch_rows_to_f32(hipStream_t s, const void* src, int src_bf16, const int32_t* src_row, float* dst, int n, int H) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(rows_to_f32_kernel, dim3(n), dim3(256), 0, s, src, src_bf16, src_row, dst, H);
+}
+template <typename TS>
+__global__ void t_to_rows_kernel(const TS* __restrict__ src, void* __restrict__ dst, int dst_bf16,
+                                 const int32_t* __restrict__ dst_row, int H) {
+    const int t = blockIdx.x;
+    const long r = dst_row ? dst_row[t] : t;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const float v = ET<TS>::ld(src + (long)t * H + i);
+        if (dst_bf16) ET<bf16>::st((bf16*)dst + r * H + i, v); else ((float*)dst)[r * H + i] = v;
+    }
+}
+void launch_f32_to_rows(hipStream_t s, const float* src, void* dst, int dst_bf16, const int32_t* dst_row, int n, int H) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(t_to_rows_kernel<float>, dim3(n), dim3(256), 0, s, src, dst, dst_bf16, dst_row, H);
+}
+template <typename T>
+void launch_t_to_rows(hipStream_t s, const T* src, void* dst, int dst_bf16, const int32_t* dst_row, int n, int H) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(t_to_rows_kernel<T>, dim3(n), dim3(256), 0, s, src, dst, dst_bf16, dst_row, H);
+}
+template void launch_t_to_rows<float>(hipStream_t, const float*, void*, int, const int32_t*, int, int);
+template void launch_t_to_rows<bf16>(hipStream_t, const bf16*, void*, int, const int32_t*, int, int);
+
+// ------------------------------------------------------------------------------- RoPE + KV append
+// grid (M tokens, nh/4), 256 threads = 4 heads x 64 rotation pairs.  rotate_half form
+// (half-split, not interleaved): out[j] = x[j]cos - x[j+64]sin, out[j+64] = x[j+64]cos + x[j]sin.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_kernel(const float* __restrict__ qkv, int S, long slab,
+                                                     T* __restrict__ qbuf, T* __restrict__ kc, T* __restrict__ vc,
+                                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                     SeqState st, int mode, int nh, int slots, int max_pos) {
+    const int m = blockIdx.x, head = blockIdx.y * 4 + (threadIdx.x >> 6), j = threadIdx.x & 63;
+    if (head >= nh) return;
+    int row, slot;
+    if (mode == 0) { row = m; slot = st.len[m] + *st.n_dec; }
+    else { row = st.tok_row[m]; slot = st.tok_j[m]; }
+    int pos = st.pos_off[row] + slot;
+    if (pos >= max_pos) pos = max_pos - 1;
+    if (slot >= slots) return;                                     // capacity guard (host checks too)
+    const int HD = nh * 128;
+    const long base = (long)m * 3 * HD + head * 128 + j;
+    float q0 = 0, q1 = 0, k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+    for (int s = 0; s < S; ++s) {
+        const float* p = qkv + (long)s * slab + base;
+        q0 += p[0]; q1 += p[64]; k0 += p[HD]; k1 += p[HD + 64]; v0 += p[2 * HD]; v1 += p[2 * HD + 64];
+    }
+    const float c = cos_t[(long)pos * 64 + j], sn = sin_t[(long)pos * 64 + j];
+    T* qo = qbuf + (long)m * HD + head * 128 + j;
+    ET<T>::st(qo, q0 * c - q1 * sn);
+    ET<T>::st(qo + 64, q1 * c + q0 * sn);
+    const long co = (((long)row * nh + head) * slots + slot) * 128 + j;
+    ET<T>::st(kc + co, k0 * c - k1 * sn);
+    ET<T>::st(kc + co + 64, k1 * c + k0 * sn);
+    ET<T>::st(vc + co, v0);
+    ET<T>::st(vc + co + 64, v1);
+}
+template <typename T>
+void launch_rope_kv(hipStream_t s, const float* qkv, int S, long slab, T* qbuf, T* kc, T* vc,
+                    const float* cos_t, const float* sin_t, SeqState st, int mode, int M, int nh,
+                    int slots, int max_pos) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(rope_kv_kernel<T>, dim3(M, (nh + 3) / 4), dim3(256), 0, s, qkv, S, slab, qbuf, kc, vc,
+                       cos_t, sin_t, st, mode, nh, slots, max_pos);
+}
+template void launch_rope_kv<float>(hipStream_t, const float*, int, long, float*, float*, float*, const float*, const float*, SeqState, int, int, int, int, int);
+template void launch_rope_kv<bf16>(hipStream_t, const float*, int, long, bf16*, bf16*, bf16*, const float*, const float*, SeqState, int, int, int, int, int);
+
+// ------------------------------------------------------------------------------- attention
+// One 256-thread block per (query, head); head_dim = 128.  HBM-bound streaming of that
+// (row, head)'s K and V (contiguous [slot][128]).  Each 16-byte vector load covers EPV
+// elements of one key; LPK = 128/EPV lanes cover a key, so one wave load instruction covers
+// KPI = 64/LPK keys (bf16: 4 keys, fp32: 2).  Every LPK-lane group runs its OWN online
+// softmax over the keys it sees (no cross-lane max exchange inside the loop); the
+// 4 waves x KPI groups partial states (m, l, o[128]) are merged once through LDS.
+template <typename T, int UN>
+__global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qbuf, T* __restrict__ obuf,
+                                                  const T* __restrict__ kc, const T* __restrict__ vc,
+                                                  SeqState st, int mode, int nh, int slots, float scale) {
+    constexpr int EPV = ET<T>::EPV, LPK = 128 / EPV, KPI = 64 / LPK, NST = 4 * KPI;
+    __shared__ float s_o[NST][128];
+    __shared__ float s_m[NST], s_l[NST];
+    const int qi = blockIdx.x, head = blockIdx.y;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int grp = l / LPK, lk = l % LPK;                // key group in wave, lane within key
+    int row, klen;
+    if (mode == 0) { row = qi; klen = st.len[qi] + *st.n_dec + 1; }
+    else { row = st.tok_row[qi]; klen = st.tok_j[qi] + 1; }
+    if (klen > slots) klen = slots;
+    const int HD = nh * 128;
+    float q[EPV];
+    {
+        const u32x4 qv = *(const u32x4*)(qbuf + (long)qi * HD + head * 128 + lk * EPV);
+        ET<T>::unpack(qv, q);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) q[e] *= scale;
+    }
+    const T* kb = kc + ((long)row * nh + head) * slots * 128 + lk * EPV;
+    const T* vb = vc + ((long)row * nh + head) * slots * 128 + lk * EPV;
+    float m_run = -INFINITY, l_run = 0.f, o[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) o[e] = 0.f;
+
+    constexpr int KPW = KPI * UN;                          // keys per wave iteration
+    for (int base = w * KPW; base < klen; base += 4 * KPW) {
+        u32x4 kv[UN], vv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int key = base + u * KPI + grp;
+            key = key < klen ? key : klen - 1;             // clamp: load stays in bounds
+            kv[u] = *(const u32x4*)(kb + (long)key * 128);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int key = base + u * KPI + grp;
+            key = key < klen ? key : klen - 1;
+            vv[u] = *(const u32x4*)(vb + (long)key * 128);
+        }
+        float sc[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float kf[EPV]; ET<T>::unpack(kv[u], kf);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) d = fmaf(q[e], kf[e], d);
+#pragma unroll
+            for (int o_ = LPK / 2; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
+            sc[u] = (base + u * KPI + grp < klen) ? d : -INFINITY;
+        }
+        float mx = m_run;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) mx = fmaxf(mx, sc[u]);
+        if (mx > -INFINITY) {
+            const float alpha = __expf(m_run - mx);        // m_run=-inf -> 0
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) o[e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float p = __expf(sc[u] - mx);        // -inf -> 0
+                l_run += p;
+                float vf[EPV]; ET<T>::unpack(vv[u], vf);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o[e] = fmaf(p, vf[e], o[e]);
+            }
+            m_run = mx;
+        }
+    }
+    const int stt = w * KPI + grp;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) s_o[stt][lk * EPV + e] = o[e];
+    if (lk == 0) { s_m[stt] = m_run; s_l[stt] = l_run; }
+    __syncthreads();
+    if (tid < 128) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) M = fmaxf(M, s_m[i]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const float f = (s_m[i] > -INFINITY) ? __expf(s_m[i] - M) : 0.f;
+            num = fmaf(f, s_o[i][tid], num);
+            den = fmaf(f, s_l[i], den);
+        }
+        ET<T>::st(obuf + (long)qi * HD + head * 128 + tid, num / den);
+    }
+}
+template <typename T>
+void launch_attn(hipStream_t s, const T* qbuf, T* obuf, const T* kc, const T* vc, SeqState st, int mode,
+                 int M, int nh, int slots, float scale) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL((attn_kernel<T, 8>), dim3(M, nh), dim3(256), 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale);
+}
+template void launch_attn<float>(hipStream_t, const float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
+template void launch_attn<bf16>(hipStream_t, const bf16*, bf16*, const bf16*, const bf16*, SeqState, int, int, int, int, float);
+
+// ------------------------------------------------------------------------------- SwiGLU gate
+// gu columns are interleaved in blocks of 16: [16 gate | 16 up] per 32 columns.
+template <typename T>
+__global__ void silu_mul_kernel(const float* __restrict__ gu, int S, long slab, T* __restrict__ h, int I) {
+    const int m = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= I) return;
+    const long cg = (long)m * 2 * I + (n >> 4) * 32 + (n & 15);
+    float g = 0.f, u = 0.f;
+    for (int s = 0; s < S; ++s) { g += gu[(long)s * slab + cg]; u += gu[(long)s * slab + cg + 16]; }
+    ET<T>::st(h + (long)m * I + n, (g / (1.f + expf(-g))) * u);
+}
+template <typename T>
+void launch_silu_mul(hipStream_t s, const float* gu, int S, long slab, T* h, int M, int I) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(silu_mul_kernel<T>, dim3((I + 255) / 256, M), dim3(256), 0, s, gu, S, slab, h, I);
+}
+template void launch_silu_mul<float>(hipStream_t, const float*, int, long, float*, int, int);
+template void launch_silu_mul<bf16>(hipStream_t, const float*, int, long, bf16*, int, int);
+
+template <typename T>
+__global__ void bias_act_kernel(const float* __restrict__ partial, int S, long slab, const float* __restrict__ bias,
+                                T* __restrict__ out, int N, int act) {
+    const int m = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float v = bias ? bias[n] : 0.f;
+    for (int s = 0; s < S; ++s) v += partial[(long)s * slab + (long)m * N + n];
+    if (act == 1) v = gelu_erf(v);
+    ET<T>::st(out + (long)m * N + n, v);
+}
+template <typename T>
+void launch_bias_act(hipStream_t s, const float* partial, int S, long slab, const float* bias, T* out,
+                     int M, int N, int act) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(bias_act_kernel<T>, dim3((N + 255) / 256, M), dim3(256), 0, s, partial, S, slab, bias, out, N, act);
+}
+template void launch_bias_act<float>(hipStream_t, const float*, int, long, const float*, float*, int, int, int);
+template void launch_bias_act<bf16>(hipStream_t, const float*, int, long, const float*, bf16*, int, int, int);
+void launch_bias_f32(hipStream_t s, const float* partial, int S, long slab, const float* bias, float* out, int M, int N) {
+    launch_bias_act<float>(s, partial, S, slab, bias, out, M, N, 0);
+}
+
+// ------------------------------------------------------------------------------- CFG + sample
+// One block per image b (rows 2b = cond, 2b+1 = uncond).  mixed = u + w (c - u)
+// (plangen_base.py:587); greedy: first index of the max (torch.argmax tie rule);
+// temperature > 0: Gumbel-max == multinomial(softmax(mixed / T)).  Then the chosen (or
+// forced) token's precomputed gen_aligner(gen_embed(tok)) row is written to both CFG rows
+// of the residual stream (plangen_base.py:602-604).
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__global__ __launch_bounds__(256) void cfg_sample_kernel(SampleArgs a) {
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
+    const int B = gridDim.x;
+    const long rc = (long)(2 * b) * a.V, ru = (long)(2 * b + 1) * a.V;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    const float invT = a.temperature > 0.f ? 1.f / a.temperature : 1.f;
+    for (int v = tid; v < a.V; v += 256) {
+        float c = a.bias ? a.bias[v] : 0.f, u = c;
+        for (int s = 0; s < a.S; ++s) {
+            c += a.logits_partial[(long)s * a.slab + rc + v];
+            u += a.logits_partial[(long)s * a.slab + ru + v];
+        }
+        float mixed = u + a.cfg_weight * (c - u);
+        if (a.logits_out) a.logits_out[((long)step * B + b) * a.V + v] = mixed;
+        if (a.temperature > 0.f) {
+            const float uu = rng_uniform(a.seed, (uint64_t)b * 1000003ull + step, v);
+            mixed = mixed * invT - __logf(-__logf(uu));
+        }
+        if (mixed > best) { best = mixed; bi = v; }           // strided ascending: keeps first max
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        argmax_combine(best, bi, ov, oi);
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float v = sv[0]; int i = si[0];
+        for (int k = 1; k < 4; ++k) argmax_combine(v, i, sv[k], si[k]);
+        int emit = i, feed = i;
+        if (step < a.T && a.force_tok) {
+            const int f = a.force_tok[(long)b * a.T + step];
+            if (a.force_mask) { if (a.force_mask[(long)b * a.T + step] == 0) { emit = f; feed = f; } }
+            else feed = f;
+        }
+        if (step < a.T) a.out_tok[(long)b * a.T + step] = emit;
+        feed = feed < 0 ? 0 : (feed >= a.V ? a.V - 1 : feed);
+        s_tok = feed;
+    }
+    __syncthreads();
+    const float* src = a.embed_table + (long)s_tok * a.H;
+    float* x0 = a.x + (long)(2 * b) * a.H;
+    for (int i = tid * 4; i < a.H; i += 1024) {
+        const f32x4 v = *(const f32x4*)(src + i);
+        *(f32x4*)(x0 + i) = v;
+        *(f32x4*)(x0 + a.H + i) = v;
+    }
+}
+void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B) {
+    hipLaunchKernelGGL(cfg_sample_kernel, dim3(B), dim3(256), 0, s, a);
+}
+
+// greedy text token (HF generate, do_sample=False): argmax over vocab, finished rows emit
+// eos, unfinished &= (tok != eos).
+__global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a) {
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int v = tid; v < a.V; v += 256) {
+        float c = 0.f;
+        for (int s = 0; s < a.S; ++s) c += a.logits_partial[(long)s * a.slab + (long)b * a.V + v];
+        if (v == a.eos && step < a.min_new) c = -INFINITY;
+        if (c > best) { best = c; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        argmax_combine(best, bi, ov, oi);
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float v = sv[0]; int i = si[0];
+        for (int k = 1; k < 4; ++k) argmax_combine(v, i, sv[k], si[k]);
+        const int unf = a.unfinished[b];
+        const int tok = unf ? i : a.eos;
+        if (step < a.max_new) a.out[(long)b * a.max_new + step] = tok;
+        const int still = unf && (tok != a.eos);
+        a.unfinished[b] = still;
+        if (still) atomicOr(a.any_unfinished + ((step + 1) & 1023), 1);
+        s_tok = tok < 0 ? 0 : (tok >= a.V ? a.V - 1 : tok);
+    }
+    __syncthreads();
+    const float* src = a.embed_table + (long)s_tok * a.H;
+    float* x0 = a.x + (long)b * a.H;
+    for (int i = tid * 4; i < a.H; i += 1024) *(f32x4*)(x0 + i) = *(const f32x4*)(src + i);
+}
+void launch_text_argmax(hipStream_t s, const TextArgs& a, int B) {
+    hipLaunchKernelGGL(text_argmax_kernel, dim3(B), dim3(256), 0, s, a);
+}
+
+__global__ void advance_kernel(int32_t* n) { *n += 1; }
+void launch_advance(hipStream_t s, int32_t* n_dec) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, s, n_dec); }
+
+// ------------------------------------------------------------------------------- weight conversion
+template <typename T>
+__global__ void convert_kernel(const void* __restrict__ src, int src_bf16, T* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = src_bf16 ? ET<bf16>::ld((const bf16*)src + i) : ((const float*)src)[i];
+        ET<T>::st(dst + i, v);
+    }
+}
+template <typename T>
+void launch_convert(hipStream_t s, const void* src, int src_bf16, T* dst, long n) {
+    if (n <= 0) return;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(convert_kernel<T>, dim3(blocks), dim3(256), 0, s, src, src_bf16, dst, n);
+}
+template void launch_convert<float>(hipStream_t, const void*, int, float*, long);
+template void launch_convert<bf16>(hipStream_t, const void*, int, bf16*, long);
+void launch_to_f32(hipStream_t s, const void* src, int src_bf16, float* dst, long n) { launch_convert<float>(s, src, src_bf16, dst, n); }
+
+template <typename T>
+__global__ void convert_conv_kernel(const void* __restrict__ src, int src_bf16, T* __restrict__ dst, int Cout, int Cin, int kk) {
+    const long n = (long)Cout * Cin * kk;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // dst index i = (co*kk + tap)*Cin + ci ; src index = (co*Cin + ci)*kk + tap
+        const int ci = (int)(i % Cin); const long t = i / Cin; const int tap = (int)(t % kk); const long co = t / kk;
+        const long si = (co * Cin + ci) * kk + tap;
+        const float v = src_bf16 ? ET<bf16>::ld((const bf16*)src + si) : ((const float*)src)[si];
+        ET<T>::st(dst + i, v);
+    }
+}
+template <typename T>
+void launch_convert_conv(hipStream_t s, const void* src, int src_bf16, T* dst, int Cout, int Cin, int kk) {
+    const long n = (long)Cout * Cin * kk;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(convert_conv_kernel<T>, dim3(blocks), dim3(256), 0, s, src, src_bf16, dst, Cout, Cin, kk);
+}
+template void launch_convert_conv<float>(hipStream_t, const void*, int, float*, int, int, int);
+template void launch_convert_conv<bf16>(hipStream_t, const void*, int, bf16*, int, int, int);
+
+template <typename T>
+__global__ void convert_il16_kernel(const void* __restrict__ src, int src_bf16, T* __restrict__ dst, int I, int H, int which) {
+    const long n = (long)I * H;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / H; const int c = (int)(i % H);
+        const long dr = (r >> 4) * 32 + which * 16 + (r & 15);
+        const float v = src_bf16 ? ET<bf16>::ld((const bf16*)src + i) : ((const float*)src)[i];
+        ET<T>::st(dst + dr * H + c, v);
+    }
+}
+template <typename T>
+void launch_convert_interleave16(hipStream_t s, const void* src, int src_bf16, T* dst, int I, int H, int which) {
+    const long n = (long)I * H;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(convert_il16_kernel<T>, dim3(blocks), dim3(256), 0, s, src, src_bf16, dst, I, H, which);
+}
+template void launch_convert_interleave16<float>(hipStream_t, const void*, int, float*, int, int, int);
+template void launch_convert_interleave16<bf16>(hipStream_t, const void*, int, bf16*, int, int, int);
+
+__global__ void l2norm_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int D) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float ss = 0.f;
+    for (int d = 0; d < D; ++d) ss += src[(long)r * D + d] * src[(long)r * D + d];
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);                   // F.normalize eps
+    for (int d = 0; d < D; ++d) dst[(long)r * D + d] = src[(long)r * D + d] / nrm;
+}
+void launch_l2norm_rows(hipStream_t s, const float* src, float* dst, int n, int D) {
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n, D);
+}
+void launch_fill_zero(hipStream_t s, void* p, long bytes) { (void)hipMemsetAsync(p, 0, bytes, s); }

@@ -1,0 +1,259 @@
+// VQ-16 tokenizer kernels other than the implicit-GEMM convolutions (those are gemm.hip's
+// ConvLoader): code -> post_quant table gather, GroupNorm(32) statistics and apply(+swish),
+// row softmax for the single-head AttnBlock, the Cout=3 output conv, the Cin=3 input conv and
+// the nearest-code argmin of the encoder.  Activations are NHWC (channels contiguous) so a
+// pixel's channels are one coalesced run.  Reference: three_party/Janus/janus/models/vq_model.py.
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------- gather
+template <typename T>
+__global__ void vq_gather_kernel(const T* __restrict__ table, const int32_t* __restrict__ codes,
+                                 T* __restrict__ out, int C, int vocab) {
+    const int p = blockIdx.x;
+    int c = codes[p];
+    c = c < 0 ? 0 : (c >= vocab ? vocab - 1 : c);
+    for (int i = threadIdx.x; i < C; i += blockDim.x) out[(long)p * C + i] = table[(long)c * C + i];
+}
+template <typename T>
+void launch_vq_gather(hipStream_t s, const T* table, const int32_t* codes, T* out, int n, int C, int vocab) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(vq_gather_kernel<T>, dim3(n), dim3(64), 0, s, table, codes, out, C, vocab);
+}
+template void launch_vq_gather<float>(hipStream_t, const float*, const int32_t*, float*, int, int, int);
+template void launch_vq_gather<bf16>(hipStream_t, const bf16*, const int32_t*, bf16*, int, int, int);
+
+// ------------------------------------------------------------------------------- GroupNorm stats
+// grid (nsplit, B), 256 threads.  Thread -> (pixel lane, 16-byte channel vector); per-thread
+// per-channel fp32 partial sums, deterministic LDS tree (no atomics), per-(split, group)
+// partials to ws, then a finalize kernel combines the splits in double.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ ws,
+                                                      int HW, int C, int nsplit) {
+    constexpr int EPV = ET<T>::EPV;
+    extern __shared__ float lds[];                    // [2][PL][C]
+    const int b = blockIdx.y, sp = blockIdx.x, tid = threadIdx.x;
+    const int VPP = C / EPV;                          // vectors per pixel (divides 256 or C > 256*EPV handled by loop)
+    const int per = (HW + nsplit - 1) / nsplit;
+    const int p0 = sp * per, p1 = min(HW, p0 + per);
+    const int PL = 256 / VPP > 0 ? 256 / VPP : 1;     // pixel lanes
+    const int vi = tid % VPP, pl = tid / VPP;
+    float s[EPV], q[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (pl < PL && VPP <= 256) {
+        const T* xb = x + (long)b * HW * C + vi * EPV;
+        for (int p = p0 + pl; p < p1; p += PL) {
+            const u32x4 v = *(const u32x4*)(xb + (long)p * C);
+            float f[EPV]; ET<T>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { s[e] += f[e]; q[e] = fmaf(f[e], f[e], q[e]); }
+        }
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            lds[(0 * PL + pl) * C + vi * EPV + e] = s[e];
+            lds[(1 * PL + pl) * C + vi * EPV + e] = q[e];
+        }
+    }
+    __syncthreads();
+    // per-channel reduce over pixel lanes, then per-group over its channels (thread per group)
+    const int cpg = C / 32;
+    if (tid < 32) {
+        float gs = 0.f, gq = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c)
+            for (int j = 0; j < PL; ++j) { gs += lds[(0 * PL + j) * C + c]; gq += lds[(1 * PL + j) * C + c]; }
+        float* o = ws + (((long)b * nsplit + sp) * 32 + tid) * 2;
+        o[0] = gs; o[1] = gq;
+    }
+}
+__global__ void gn_finalize_kernel(const float* __restrict__ ws, float* __restrict__ stats, int nsplit, double cnt, float eps) {
+    const int b = blockIdx.x, g = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float* o = ws + (((long)b * nsplit + sp) * 32 + g) * 2;
+        s += (double)o[0]; q += (double)o[1];
+    }
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((long)b * 32 + g) * 2 + 0] = (float)mean;
+    stats[((long)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+static int gn_nsplit(int HW) { int n = (HW + 1023) / 1024; return n < 1 ? 1 : (n > 256 ? 256 : n); }
+void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, float* ws, int B, int HW, int C, float eps) {
+    const int nsplit = gn_nsplit(HW);
+    const int EPV = is_bf16 ? 8 : 4;
+    const int VPP = C / EPV, PL = 256 / VPP > 0 ? 256 / VPP : 1;
+    const size_t lds = (size_t)2 * PL * C * sizeof(float);
+    if (is_bf16) hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(nsplit, B), dim3(256), lds, s, (const bf16*)x, ws, HW, C, nsplit);
+    else hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nsplit, B), dim3(256), lds, s, (const float*)x, ws, HW, C, nsplit);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(32), 0, s, ws, stats, nsplit, (double)HW * (C / 32), eps);
+}
+
+template <typename T>
+__global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                T* __restrict__ y, long HWC, int C, int swish, long total_vec) {
+    constexpr int EPV = ET<T>::EPV;
+    const int cpg = C / 32;
+    for (long vi = (long)blockIdx.x * blockDim.x + threadIdx.x; vi < total_vec; vi += (long)gridDim.x * blockDim.x) {
+        const long e0 = vi * EPV;
+        const int b = (int)(e0 / HWC);
+        const int c0 = (int)(e0 % C);
+        const u32x4 v = *(const u32x4*)(x + e0);
+        float f[EPV]; ET<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const int c = c0 + e, g = c / cpg;
+            const float mean = stats[((long)b * 32 + g) * 2], rstd = stats[((long)b * 32 + g) * 2 + 1];
+            float t = (f[e] - mean) * rstd * gamma[c] + beta[c];
+            if (swish) t = t / (1.f + expf(-t));
+            f[e] = t;
+        }
+        *(u32x4*)(y + e0) = ET<T>::pack(f);
+    }
+}
+template <typename T>
+void launch_gn_apply(hipStream_t s, const T* x, const float* stats, const float* gamma, const float* beta,
+                     T* y, int B, int HW, int C, int swish) {
+    const long total_vec = (long)B * HW * C / ET<T>::EPV;
+    const int blocks = (int)((total_vec + 255) / 256 < 8192 ? (total_vec + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, y, (long)HW * C, C, swish, total_vec);
+}
+template void launch_gn_apply<float>(hipStream_t, const float*, const float*, const float*, const float*, float*, int, int, int, int);
+template void launch_gn_apply<bf16>(hipStream_t, const bf16*, const float*, const float*, const float*, bf16*, int, int, int, int);
+
+// ------------------------------------------------------------------------------- row softmax
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, T* __restrict__ y, int rows, int n, float scale) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* xr = x + (long)r * n;
+    float mx = -INFINITY;
+    for (int i = l; i < n; i += 64) mx = fmaxf(mx, xr[i] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = l; i < n; i += 64) sum += expf(xr[i] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int i = l; i < n; i += 64) ET<T>::st(y + (long)r * n + i, expf(xr[i] * scale - mx) * inv);
+}
+template <typename T>
+void launch_softmax_rows(hipStream_t s, const float* x, T* y, int rows, int n, float scale) {
+    hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3((rows + 3) / 4), dim3(256), 0, s, x, y, rows, n, scale);
+}
+template void launch_softmax_rows<float>(hipStream_t, const float*, float*, int, int, float);
+template void launch_softmax_rows<bf16>(hipStream_t, const float*, bf16*, int, int, float);
+
+// ------------------------------------------------------------------------------- conv_out (Cout tiny)
+// Thread per output pixel, all Cout (<= 4) channels; weights fp32 in LDS; NHWC in, NCHW out.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                           const float* __restrict__ bias, void* __restrict__ out,
+                                                           int out_bf16, int H, int W, int Cin, int Cout) {
+    constexpr int EPV = ET<T>::EPV;
+    extern __shared__ float wl[];                        // [Cout][9][Cin]
+    const int nw = Cout * 9 * Cin;
+    for (int i = threadIdx.x; i < nw; i += 256) wl[i] = ET<T>::ld(w + i);
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, xx = p % W;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < 9; ++tap) {
+        const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
+        if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+        const T* xp = x + (((long)b * H + sy) * W + sx) * Cin;
+        for (int c = 0; c < Cin; c += EPV) {
+            const u32x4 v = *(const u32x4*)(xp + c);
+            float f[EPV]; ET<T>::unpack(v, f);
+#pragma unroll
+            for (int co = 0; co < 4; ++co) {
+                if (co < Cout) {
+                    const float* wp = wl + (co * 9 + tap) * Cin + c;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) acc[co] = fmaf(f[e], wp[e], acc[co]);
+                }
+            }
+        }
+    }
+    for (int co = 0; co < Cout; ++co) {
+        const float v = acc[co] + bias[co];
+        const long o = (((long)b * Cout + co) * H + y) * W + xx;
+        if (out_bf16) ET<bf16>::st((bf16*)out + o, v); else ((float*)out)[o] = v;
+    }
+}
+template <typename T>
+void launch_conv3x3_small(hipStream_t s, const T* x, const T* w, const float* bias, void* out, int out_bf16,
+                          int B, int H, int W, int Cin, int Cout) {
+    hipLaunchKernelGGL(conv3x3_small_kernel<T>, dim3((H * W + 255) / 256, B), dim3(256), (size_t)Cout * 9 * Cin * sizeof(float), s,
+                       x, w, bias, out, out_bf16, H, W, Cin, Cout);
+}
+template void launch_conv3x3_small<float>(hipStream_t, const float*, const float*, const float*, void*, int, int, int, int, int, int);
+template void launch_conv3x3_small<bf16>(hipStream_t, const bf16*, const bf16*, const float*, void*, int, int, int, int, int, int);
+
+// ------------------------------------------------------------------------------- conv_in (Cin tiny)
+// Encoder conv_in 3 -> ch: NCHW input, NHWC T output; thread per (pixel, cout).
+template <typename T>
+__global__ void conv3x3_in_kernel(const void* __restrict__ x, int x_bf16, const float* __restrict__ w,
+                                  const float* __restrict__ bias, T* __restrict__ out, int H, int W, int Cin, int Cout) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)H * W * Cout) return;
+    const int co = (int)(i % Cout); const int p = (int)(i / Cout); const int y = p / W, xx = p % W;
+    float acc = bias[co];
+    for (int ci = 0; ci < Cin; ++ci)
+        for (int tap = 0; tap < 9; ++tap) {
+            const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
+            if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+            const long xi = (((long)b * Cin + ci) * H + sy) * W + sx;
+            const float v = x_bf16 ? ET<bf16>::ld((const bf16*)x + xi) : ((const float*)x)[xi];
+            acc = fmaf(v, w[((long)co * Cin + ci) * 9 + tap], acc);
+        }
+    ET<T>::st(out + ((long)b * H * W + p) * Cout + co, acc);
+}
+template <typename T>
+void launch_conv3x3_in(hipStream_t s, const void* x, int x_bf16, const float* w, const float* bias, T* out,
+                       int B, int H, int W, int Cin, int Cout) {
+    const long n = (long)H * W * Cout;
+    hipLaunchKernelGGL(conv3x3_in_kernel<T>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, x, x_bf16, w, bias, out, H, W, Cin, Cout);
+}
+template void launch_conv3x3_in<float>(hipStream_t, const void*, int, const float*, const float*, float*, int, int, int, int, int);
+template void launch_conv3x3_in<bf16>(hipStream_t, const void*, int, const float*, const float*, bf16*, int, int, int, int, int);
+
+// ------------------------------------------------------------------------------- nearest code
+// VectorQuantizer.forward (vq_model.py:236-258): z and codebook L2-normalised,
+// d = |z|^2 + |e|^2 - 2 z.e, argmin (first minimum).  One block per latent vector.
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                       int64_t* __restrict__ idx, int D, int V) {
+    __shared__ float sv[4]; __shared__ int si[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    float zn[8]; float ss = 0.f;
+    for (int d = 0; d < D; ++d) { zn[d] = z[(long)r * D + d]; ss += zn[d] * zn[d]; }
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    float zz = 0.f;
+    for (int d = 0; d < D; ++d) { zn[d] /= nrm; zz += zn[d] * zn[d]; }
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        float ee = 0.f, dot = 0.f;
+        for (int d = 0; d < D; ++d) { const float e = cb[(long)v * D + d]; ee += e * e; dot += zn[d] * e; }
+        const float dist = zz + ee - 2.f * dot;
+        if (dist < best) { best = dist; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float v = sv[0]; int i = si[0];
+        for (int k = 1; k < 4; ++k) if (sv[k] < v || (sv[k] == v && si[k] < i)) { v = sv[k]; i = si[k]; }
+        idx[r] = i;
+    }
+}
+void launch_vq_argmin(hipStream_t s, const float* z, const float* codebook, int64_t* idx, int n, int D, int V) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(vq_argmin_kernel, dim3(n), dim3(256), 0, s, z, codebook, idx, D, V);
+}

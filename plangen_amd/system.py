@@ -1,0 +1,168 @@
+"""Host-side mirror of the inference methods of PlanGen's ``System``
+(project/plangen/plangen_base.py): same names, argument meaning and tensor contracts for
+``pad_input_ids`` (:699-725), ``t2i_infer_collate_batch`` (:636-697), ``t2i`` (:525-565),
+``sample_image`` (:567-607) and ``x2t`` (:513-523), running on the MI355X engine.
+
+The tokenizer (HF LlamaTokenizerFast files) is not part of the path, so prompts enter as
+token-id lists -- what ``wrap_uni_prompt`` returns (:232-261).
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .config import PlanGenConfig
+from .engine import Engine, PlanGenError
+from .janus import MultiModalityCausalLM
+
+
+def pad_input_ids(all_inputs_ids: Sequence[Sequence[int]], pad_id: int, max_length: Optional[int] = None,
+                  debug_max_seq_len: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """System.pad_input_ids, test-mode branch: LEFT-pad to the longest (or forced) length."""
+    bs = len(all_inputs_ids)
+    if debug_max_seq_len is not None:
+        max_length = debug_max_seq_len
+    if max_length is None:
+        max_length = max(map(len, all_inputs_ids))
+    ids = torch.full((bs, max_length), pad_id, dtype=torch.int32)
+    mask = torch.zeros((bs, max_length), dtype=torch.int32)
+    for i, t in enumerate(all_inputs_ids):
+        n = len(t)
+        if n > max_length:
+            raise PlanGenError(f"prompt {i} has {n} tokens > max_length {max_length}")
+        if n:
+            ids[i, max_length - n:] = torch.as_tensor(list(t), dtype=torch.int32)
+            mask[i, max_length - n:] = 1
+    return ids, mask
+
+
+def t2i_infer_collate_batch(cond_ids: Sequence[Sequence[int]], neg_ids, pad_id: int, img_tokens: int,
+                            debug_max_seq_len: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """System.t2i_infer_collate_batch: CFG pairs.  ``neg_ids`` is one shared negative prompt
+    (``use_neg_box=False``, :672-686) or one per sample (``use_neg_box=True``, :652-670).
+    Returns cfg_inputs_ids int32 [2B, L] (row 2k cond, 2k+1 uncond, :690-691) and
+    cfg_attention_mask int32 [2B, L+img_tokens] (image part all ones, :778)."""
+    bs = len(cond_ids)
+    per_sample = len(neg_ids) > 0 and isinstance(neg_ids[0], (list, tuple, torch.Tensor))
+    negs = [list(n) for n in neg_ids] if per_sample else [list(neg_ids)] * bs
+    if len(negs) != bs:
+        raise PlanGenError("one negative prompt per sample expected")
+    L = max(max(map(len, cond_ids)), max(map(len, negs)))
+    if debug_max_seq_len is not None:
+        L = debug_max_seq_len
+    c_ids, c_mask = pad_input_ids(cond_ids, pad_id, L)
+    n_ids, n_mask = pad_input_ids(negs, pad_id, L)
+    ones = torch.ones((bs, img_tokens), dtype=torch.int32)
+    ids = torch.stack([c_ids, n_ids], dim=1).view(bs * 2, -1)
+    mask = torch.stack([torch.cat([c_mask, ones], -1), torch.cat([n_mask, ones], -1)], dim=1).view(bs * 2, -1)
+    return ids.int(), mask.int()
+
+
+def denorm_pt(pt: torch.Tensor) -> torch.Tensor:
+    """src/utils/funcs.py:511."""
+    return (pt.clamp(-1, 1) + 1) / 2
+
+
+class System:
+    """Inference half of PlanGen's System on one MI355X.
+
+    args carries the cfg keys the path reads (cfg/base.py): seed, parallel_size, cfg_weight,
+    temperature, use_teacher_forcing, debug_max_seq_len, janus_hw.
+    """
+
+    def __init__(self, cfg: PlanGenConfig, engine: Engine, args: Optional[SimpleNamespace] = None):
+        self.cfg = cfg
+        self.engine = engine
+        self.vl_gpt = MultiModalityCausalLM(engine)
+        self.args = args or SimpleNamespace(seed=cfg.seed, parallel_size=1, cfg_weight=cfg.cfg_weight,
+                                            temperature=cfg.temperature, use_teacher_forcing=False,
+                                            debug_max_seq_len=None, janus_hw=cfg.img_size)
+        self.image_token_num_per_image = cfg.img_tokens
+        self.device = engine.device
+
+    # -------------------------------------------------------------- collate
+    def pad_input_ids(self, all_inputs_ids, max_length=None):
+        return pad_input_ids(all_inputs_ids, self.cfg.pad_id, max_length, self.args.debug_max_seq_len)
+
+    def t2i_infer_collate_batch(self, cond_ids, neg_ids):
+        return t2i_infer_collate_batch(cond_ids, neg_ids, self.cfg.pad_id, self.image_token_num_per_image,
+                                       self.args.debug_max_seq_len)
+
+    # -------------------------------------------------------------- hot path
+    @torch.no_grad()
+    def sample_image(self, tokens: torch.Tensor, mask: torch.Tensor, cfg_weight: float, temperature: float,
+                     seed: int = 0, edit_region: Optional[torch.Tensor] = None,
+                     gt_labels: Optional[torch.Tensor] = None, force_tokens: Optional[torch.Tensor] = None,
+                     n_tokens: Optional[int] = None, return_logits: bool = False):
+        """The 576-step CFG loop, fused on device (one pg_prefill + one pg_decode_image_tokens).
+        tokens int32 [2B, L] CFG-interleaved ids, mask [2B, L+T].  temperature<=0 -> greedy."""
+        L = tokens.shape[1]
+        pad = Engine.pad_len_from_mask(mask, L)
+        self.engine.prefill(tokens, pad, position_mode=0)
+        fm = ft = None
+        if edit_region is not None:                        # use_teacher_forcing branch (:593-598)
+            ft, fm = gt_labels, (edit_region != 0).to(torch.uint8)
+        elif force_tokens is not None:
+            ft = force_tokens
+        return self.engine.decode_image_tokens(n_tokens, cfg_weight, temperature, seed, ft, fm, return_logits)
+
+    @torch.no_grad()
+    def sample_image_stepwise(self, inputs_embeds: torch.Tensor, mask: torch.Tensor, cfg_weight: float,
+                              n_tokens: Optional[int] = None) -> torch.Tensor:
+        """The reference's own loop shape (:567-607) through the drop-in facade, greedy: one
+        ``language_model.model`` call + ``gen_head`` + ``prepare_gen_img_embeds`` per token."""
+        T = self.image_token_num_per_image if n_tokens is None else n_tokens
+        num_gen = inputs_embeds.shape[0] // 2
+        generated = torch.zeros((num_gen, T), dtype=torch.int, device=self.device)
+        outputs = None
+        for i in range(T):
+            outputs = self.vl_gpt.language_model.model(inputs_embeds=inputs_embeds, attention_mask=mask, use_cache=True,
+                                                       past_key_values=outputs.past_key_values if i != 0 else None)
+            hidden_states = outputs.last_hidden_state
+            logits = self.vl_gpt.gen_head(hidden_states[:, -1, :])
+            logit_cond, logit_uncond = logits[0::2, :], logits[1::2, :]
+            logits = logit_uncond + cfg_weight * (logit_cond - logit_uncond)
+            next_token = torch.argmax(logits, dim=-1, keepdim=True)
+            generated[:, i] = next_token.squeeze(-1)
+            next_token = torch.cat([next_token.unsqueeze(1), next_token.unsqueeze(1)], dim=1).view(-1)
+            inputs_embeds = self.vl_gpt.prepare_gen_img_embeds(next_token).unsqueeze(1)
+        return generated
+
+    @torch.no_grad()
+    def t2i(self, tokens: torch.Tensor, mask: torch.Tensor, cfg_weight: Optional[float] = None,
+            temperature: Optional[float] = None, gt_image: Optional[torch.Tensor] = None,
+            edit_region: Optional[torch.Tensor] = None, parallel_size: Optional[int] = None):
+        """System.t2i: (teacher forcing: VQ-encode the ground truth :528-532) -> replicate x
+        parallel_size (:547) -> sample_image -> decode_code (:555).  Returns (dec [B*p,3,S,S]
+        fp32, generated_tokens int32 [B*p, T])."""
+        a = self.args
+        cfg_weight = a.cfg_weight if cfg_weight is None else cfg_weight
+        temperature = a.temperature if temperature is None else temperature
+        p = a.parallel_size if parallel_size is None else parallel_size
+        gt_labels = None
+        if a.use_teacher_forcing and gt_image is not None:
+            bs = gt_image.shape[0]
+            gt_labels = self.vl_gpt.gen_vision_model.encode(gt_image)[-1][-1].reshape(bs, -1).to(torch.int32)
+        if p > 1:
+            tokens = torch.cat([tokens] * p)
+            mask = torch.cat([mask] * p)
+            if gt_labels is not None:
+                gt_labels = torch.cat([gt_labels] * p)
+                edit_region = torch.cat([edit_region] * p)
+        toks = self.sample_image(tokens, mask, cfg_weight, temperature, a.seed,
+                                 edit_region if gt_labels is not None else None, gt_labels)
+        num_gen = tokens.shape[0] // 2
+        dec = self.vl_gpt.gen_vision_model.decode_code(toks.to(dtype=torch.int),
+                                                       shape=[num_gen, self.cfg.img_dim, self.cfg.grid, self.cfg.grid])
+        return dec, toks
+
+    @torch.no_grad()
+    def x2t(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+            max_new_tokens: int = 512, min_new_tokens: int = 0) -> torch.Tensor:
+        """System.x2t (:513-523): greedy text / layout-token decode."""
+        return self.vl_gpt.language_model.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask,
+                                                   pad_token_id=self.cfg.eos_id, bos_token_id=None,
+                                                   eos_token_id=self.cfg.eos_id, max_new_tokens=max_new_tokens,
+                                                   do_sample=False, use_cache=True, min_new_tokens=min_new_tokens)

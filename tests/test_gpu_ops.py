@@ -1,0 +1,92 @@
+"""GPU: operator-level parity of the HIP kernels (through the C ABI) against plain torch
+fp32 references on the same seeded inputs.  Asymmetric random data so transposed MFMA
+layouts cannot pass."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import get_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng(tiny_cfg, tiny_weights, dtype):
+    return get_engine(tiny_cfg, tiny_weights, dtype)
+
+
+def _round(t, dtype):
+    return t.to(torch.bfloat16).float() if dtype == "bf16" else t
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_rmsnorm_with_splitk_partials(tiny_cfg, tiny_weights, dtype):
+    e = _eng(tiny_cfg, tiny_weights, dtype)
+    g = torch.Generator().manual_seed(0)
+    M, H = 5, 256
+    x = torch.randn(M, H, generator=g)
+    part = torch.randn(3, M, H, generator=g)
+    w = _round(1 + 0.1 * torch.randn(H, generator=g), dtype)
+    xnew, out = e.op_rmsnorm(x, w, 1e-6, part)
+    xr = x + part.sum(0)
+    ref = w * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert torch.allclose(xnew.cpu(), xr, atol=1e-5)
+    tol = 1e-5 if dtype == "f32" else 2e-2
+    assert (out.float().cpu() - ref).abs().max() < tol * ref.abs().max()
+
+
+@pytest.mark.parametrize("dtype,kind,M,N,K", [
+    ("f32", 3, 37, 200, 72), ("f32", 3, 130, 64, 256),
+    ("bf16", 1, 16, 768, 256), ("bf16", 1, 6, 256, 512), ("bf16", 1, 128, 512, 512), ("bf16", 1, 100, 1024, 256),
+    ("bf16", 1, 200, 256, 256),
+    ("bf16", 2, 300, 384, 192), ("bf16", 2, 128, 128, 64), ("bf16", 2, 1000, 200, 576), ("bf16", 2, 2048, 1024, 256),
+])
+def test_gemm_kinds(tiny_cfg, tiny_weights, dtype, kind, M, N, K):
+    e = _eng(tiny_cfg, tiny_weights, dtype)
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = _round(torch.randn(M, K, generator=g), dtype)
+    w = _round(torch.randn(N, K, generator=g) * torch.linspace(0.5, 2.0, N)[:, None], dtype)   # asymmetric
+    out = e.op_gemm(a, w, kind).cpu()
+    ref = a.double() @ w.double().t()
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-4 * ref.abs().max().item() + 1e-4, err
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("up,stride2,res", [(0, 0, False), (0, 0, True), (1, 0, False), (0, 1, False)])
+def test_conv3x3_implicit_gemm(tiny_cfg, tiny_weights, dtype, up, stride2, res):
+    e = _eng(tiny_cfg, tiny_weights, dtype)
+    g = torch.Generator().manual_seed(3 + up + 2 * stride2)
+    B, Hs, Ws, Cin, Cout = 2, 10, 12, 64, 128
+    x = _round(torch.randn(B, Cin, Hs, Ws, generator=g), dtype)
+    w = _round(torch.randn(Cout, Cin, 3, 3, generator=g) / 24, dtype)
+    b = torch.randn(Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    if stride2:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, b, stride=2)
+    else:
+        ref = F.conv2d(xin, w, b, padding=1)
+    r = None
+    if res:
+        r = _round(torch.randn(ref.shape, generator=g), dtype)
+        ref = ref + r
+    out = e.op_conv3x3(x.permute(0, 2, 3, 1).contiguous(), w, b, None if r is None else r.permute(0, 2, 3, 1).contiguous(),
+                       up, stride2)
+    out = out.float().cpu().permute(0, 3, 1, 2)
+    tol = 1e-4 if dtype == "f32" else 2e-2
+    assert (out - ref).abs().max() < tol * ref.abs().max()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("C,swish", [(64, True), (128, False), (512, True)])
+def test_groupnorm_swish(tiny_cfg, tiny_weights, dtype, C, swish):
+    e = _eng(tiny_cfg, tiny_weights, dtype)
+    g = torch.Generator().manual_seed(C)
+    B, Hs, Ws = 2, 9, 7
+    x = _round(torch.randn(B, C, Hs, Ws, generator=g) * 2 + 0.5, dtype)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, eps=1e-6)
+    if swish:
+        ref = ref * torch.sigmoid(ref)
+    out = e.op_groupnorm(x.permute(0, 2, 3, 1).contiguous(), gamma, beta, swish).float().cpu().permute(0, 3, 1, 2)
+    tol = 2e-5 if dtype == "f32" else 2e-2
+    assert (out - ref).abs().max() < tol * max(1.0, ref.abs().max().item())

@@ -1,0 +1,96 @@
+"""CPU: host-side logic of the product package (no GPU compute): collate semantics vs the
+oracle's restatement, config, mask handling, and that the C-ABI library loads and exports
+every symbol include/plangen_hip.h declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import ref_cpu as R
+from plangen_amd import _lib
+from plangen_amd.config import PlanGenConfig
+from plangen_amd.system import pad_input_ids, t2i_infer_collate_batch
+
+
+def test_config_shapes():
+    c = PlanGenConfig.janus_pro_1b()
+    assert (c.img_tokens, c.img_size, c.hidden, c.inter, c.n_layers) == (576, 384, 2048, 5632, 24)
+    t = PlanGenConfig.tiny()
+    assert t.img_tokens == 64 and t.img_size == 32
+    assert set(t.model_dict()) == set(R.OracleCfg().__dataclass_fields__)
+
+
+def test_pad_input_ids_left_pads_like_reference():
+    prompts = [[5, 6, 7], [9], [1, 2, 3, 4, 5]]
+    ids, mask = pad_input_ids(prompts, pad_id=3)
+    rid, rmask = R.pad_input_ids(prompts, 3)
+    assert torch.equal(ids, rid) and torch.equal(mask, rmask)
+    ids2, _ = pad_input_ids(prompts, pad_id=3, debug_max_seq_len=8)      # cfg debug_max_seq_len
+    assert ids2.shape == (3, 8) and (ids2[:, :3] == 3).all()
+    with pytest.raises(Exception):
+        pad_input_ids(prompts, pad_id=3, max_length=2)
+
+
+@pytest.mark.parametrize("neg_len", [2, 6, 9])
+def test_cfg_collate_matches_oracle(neg_len):
+    g = torch.Generator().manual_seed(neg_len)
+    cond = [torch.randint(8, 500, (n,), generator=g).tolist() for n in (7, 3, 5)]
+    neg = torch.randint(8, 500, (neg_len,), generator=g).tolist()
+    ids, mask = t2i_infer_collate_batch(cond, neg, 3, 64)
+    rid, rmask = R.t2i_infer_collate_batch(cond, neg, 3, 64)
+    assert torch.equal(ids, rid) and torch.equal(mask, rmask)
+    assert ids.shape[0] == 6 and mask.shape[1] == ids.shape[1] + 64
+
+
+def test_collate_reproduces_golden_fixture():
+    g = load_golden("sample_image_tiny.npz")
+    ids, mask = t2i_infer_collate_batch([list(c) for c in g["cond"]], g["neg"].tolist(), 3, 64)
+    assert np.array_equal(ids.numpy(), g["ids"]) and np.array_equal(mask.numpy(), g["mask"])
+
+
+def test_per_sample_negative_prompts():
+    cond = [[5, 6, 7, 8], [9, 10]]
+    negs = [[1, 2], [3, 4, 5, 6, 7]]
+    ids, mask = t2i_infer_collate_batch(cond, negs, 0, 4)
+    assert ids.shape == (4, 5)
+    assert ids[1].tolist() == [0, 0, 0, 1, 2] and ids[3].tolist() == [3, 4, 5, 6, 7]
+    assert mask[0].tolist() == [0, 1, 1, 1, 1, 1, 1, 1, 1]
+
+
+def test_pad_len_from_mask():
+    from plangen_amd.engine import Engine, PlanGenError
+    m = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1]])
+    assert Engine.pad_len_from_mask(m, 4) == [2, 0]
+    with pytest.raises(PlanGenError):
+        Engine.pad_len_from_mask(torch.tensor([[1, 0, 1, 1]]), 4)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "plangen_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    lib = _lib.load()                       # raises if the .so is missing or a symbol is absent
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_no_cpu_fallback_without_gpu():
+    from plangen_amd.engine import Engine, PlanGenError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(PlanGenError):
+        Engine(PlanGenConfig.tiny())
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "plangen_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -1,0 +1,86 @@
+"""CPU: the oracle (oracle/ref_cpu.py) against the golden vectors produced by running the
+reference's own modules (vq_model.py, projector.py) and the transformers Llama it calls."""
+import numpy as np
+import torch
+
+from conftest import load_golden, wsum
+from oracle import ref_cpu as R
+
+
+def test_weights_stream_unchanged(tiny_weights):
+    g = load_golden("sample_image_tiny.npz")
+    W = {k: v for k, v in tiny_weights.items() if "encoder" not in k and "quant_conv" not in k.replace("post_quant_conv", "")}
+    assert abs(wsum(W) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+
+
+def test_projector_matches_reference(ocfg, tiny_weights):
+    g = load_golden("proj_tiny.npz")
+    out = R.prepare_gen_img_embeds(tiny_weights, torch.from_numpy(g["ids"]))
+    assert np.abs(out.numpy() - g["out"]).max() < 1e-6
+
+
+def test_vq_decode_matches_reference(ocfg, tiny_weights):
+    g = load_golden("vq_tiny.npz")
+    img = R.vq_decode_code(tiny_weights, ocfg, torch.from_numpy(g["codes"]))
+    assert img.shape == (2, 3, ocfg.img_size, ocfg.img_size)
+    assert np.abs(img.numpy() - g["image"]).max() < 1e-5
+    zq = R.vq_codebook_lookup(tiny_weights, ocfg, torch.from_numpy(g["codes"]))
+    assert np.abs(zq.numpy() - g["zq"]).max() < 1e-7
+
+
+def test_vq_encode_matches_reference(ocfg, tiny_weights):
+    g = load_golden("vq_tiny.npz")
+    idx = R.vq_encode(tiny_weights, ocfg, torch.from_numpy(g["enc_in"]))
+    assert np.array_equal(idx.numpy(), g["enc_idx"])
+
+
+def test_vq_full_size_matches_reference():
+    g = load_golden("vq_full.npz")
+    cfg = R.OracleCfg(n_layers=0, vocab=8)
+    W = R.make_weights(cfg, seed=2, with_lm_head=False)
+    img = R.vq_decode_code(W, cfg, torch.from_numpy(g["codes"]))
+    assert img.shape == (1, 3, 384, 384)
+    pooled = torch.nn.functional.avg_pool2d(img, 8)
+    assert np.abs(pooled.numpy() - g["pooled"]).max() < 2e-5
+    assert np.abs(img[:, :, 100:132, 200:232].numpy() - g["crop"]).max() < 2e-5
+
+
+def test_llama_prefill_matches_transformers(ocfg, tiny_weights):
+    g = load_golden("sample_image_tiny.npz")
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    pos = torch.arange(ids.shape[1])[None].expand(ids.shape[0], -1)
+    hid, _ = R.llama_forward(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, pos)
+    real = mask[:, :ids.shape[1]].bool()
+    assert (hid - torch.from_numpy(g["prefill_hidden"]))[real].abs().max() < 1e-4
+
+
+def test_collate_matches_fixture(ocfg):
+    g = load_golden("sample_image_tiny.npz")
+    cond = [list(c) for c in g["cond"]]
+    ids, mask = R.t2i_infer_collate_batch(cond, g["neg"].tolist(), ocfg.pad_id, ocfg.img_tokens)
+    assert np.array_equal(ids.numpy(), g["ids"]) and np.array_equal(mask.numpy(), g["mask"])
+    # left padding, CFG interleave, all-ones image part
+    assert (mask[:, -ocfg.img_tokens:] == 1).all()
+    assert (ids[1::2] == ids[1]).all()
+
+
+def test_sample_image_matches_hf_driven_reference_loop(ocfg, tiny_weights):
+    g = load_golden("sample_image_tiny.npz")
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    toks, logits = R.sample_image(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, 5.0, return_logits=True)
+    assert np.array_equal(toks.numpy(), g["tokens"])
+    assert np.abs(logits.numpy() - g["logits"]).max() < 1e-4
+    # teacher forcing with the model's own tokens is the identity
+    toks2 = R.sample_image(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, 5.0, n_tokens=8,
+                           force_tokens=torch.from_numpy(g["tokens"]))
+    assert np.array_equal(toks2.numpy(), g["tokens"][:, :8])
+
+
+def test_generate_matches_hf_generate(ocfg, tiny_weights):
+    g = load_golden("generate_tiny.npz")
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"])
+    out = R.generate_text_greedy(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, 10, int(g["eos"]))
+    assert np.array_equal(out.numpy(), g["out"])
+    # without an early-stopping eos the probe run is reproduced too
+    out2 = R.generate_text_greedy(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, 10, ocfg.eos_id)
+    assert np.array_equal(out2.numpy(), g["probe"])
