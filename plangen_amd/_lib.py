@@ -66,6 +66,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime; it must be the one already mapped when our library's
+    # libamdhip64 dependency is resolved, or the process ends up with two runtimes (and ours
+    # sees no device).  PyTorch is the allocator / stream provider anyway.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"plangen_amd: HIP library not found at {LIB_PATH}. Build it with "
