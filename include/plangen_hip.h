@@ -185,7 +185,8 @@ int pg_op_gemm(pg_handle h, const void* a_dev /*[M,K]*/, const void* w_dev /*[N,
  * the input in; stride2=1 is the encoder's pad-(0,1,0,1) stride-2 form. */
 int pg_op_conv3x3(pg_handle h, const void* x_dev, const void* w_dev, const float* bias_dev, const void* residual_dev,
                   void* out_dev, int B, int Hi, int Wi, int Cin, int Cout, int up, int stride2, pg_stream s);
-/* GroupNorm(32, eps=1e-6) (+ optional swish) over NHWC activations (vq_model.py:393-403). */
+/* GroupNorm(32, eps=1e-6) (+ optional swish) over NHWC activations (vq_model.py:393-403):
+ * x_dev fp32 (the VQ skip stream is kept in fp32), out_dev compute dtype. */
 int pg_op_groupnorm(pg_handle h, const void* x_dev, const float* gamma_dev, const float* beta_dev, void* out_dev, int B,
                     int HW, int C, int swish, pg_stream s);
 

@@ -79,7 +79,8 @@ struct Epi {
         if (e.bias_m) v += e.bias_m[row];
         if (e.residual) {
             const long ldr = e.ldr ? e.ldr : e.ldc;
-            v += ET<T>::ld((const T*)e.residual + (long)batch * e.strideR + (long)row * ldr + col);
+            const long ro = (long)batch * e.strideR + (long)row * ldr + col;
+            v += e.res_f32 ? ((const float*)e.residual)[ro] : ET<T>::ld((const T*)e.residual + ro);
         }
         if (e.act == 1) v = gelu_erf(v);
         const long o = (long)batch * e.strideC + (long)row * e.ldc + col;

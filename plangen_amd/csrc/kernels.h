@@ -26,7 +26,8 @@ struct GemmEpi {
     long ldc = 0, strideC = 0;
     const float* bias_n = nullptr;
     const float* bias_m = nullptr;
-    const void* residual = nullptr;     // T, same ldc/stride layout as out unless ldr set
+    const void* residual = nullptr;     // T (or fp32 when res_f32), same ldc/stride layout as out unless ldr set
+    int res_f32 = 0;
     long ldr = 0, strideR = 0;
     float scale = 1.f;
     int act = 0;                        // 0 none, 1 gelu(erf)
@@ -117,9 +118,9 @@ void launch_vq_gather(hipStream_t s, const T* table, const int32_t* codes, T* ou
 // GroupNorm(32, eps) statistics: stats fp32 [B,32,2] = (mean, rstd); ws fp32 scratch >= B*32*2*nsplit
 void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, float* ws, int B, int HW, int C, float eps);
 // y = gn(x)*gamma+beta, optional swish
-template <typename T>
-void launch_gn_apply(hipStream_t s, const T* x, const float* stats, const float* gamma, const float* beta,
-                     T* y, int B, int HW, int C, int swish);
+template <typename TI, typename TO>
+void launch_gn_apply(hipStream_t s, const TI* x, const float* stats, const float* gamma, const float* beta,
+                     TO* y, int B, int HW, int C, int swish);
 // softmax over rows of fp32 [rows, n] * scale -> T
 template <typename T>
 void launch_softmax_rows(hipStream_t s, const float* x, T* y, int rows, int n, float scale);

@@ -89,18 +89,25 @@ void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, fl
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(32), 0, s, ws, stats, nsplit, (double)HW * (C / 32), eps);
 }
 
-template <typename T>
-__global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+// Input TI (fp32 skip stream or T), output TO; EPV elements of the OUTPUT type per thread.
+template <typename TI, typename TO>
+__global__ void gn_apply_kernel(const TI* __restrict__ x, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                T* __restrict__ y, long HWC, int C, int swish, long total_vec) {
-    constexpr int EPV = ET<T>::EPV;
+                                TO* __restrict__ y, long HWC, int C, int swish, long total_vec) {
+    constexpr int EPV = ET<TO>::EPV;
     const int cpg = C / 32;
     for (long vi = (long)blockIdx.x * blockDim.x + threadIdx.x; vi < total_vec; vi += (long)gridDim.x * blockDim.x) {
         const long e0 = vi * EPV;
         const int b = (int)(e0 / HWC);
         const int c0 = (int)(e0 % C);
-        const u32x4 v = *(const u32x4*)(x + e0);
-        float f[EPV]; ET<T>::unpack(v, f);
+        float f[EPV];
+        if constexpr (sizeof(TI) == sizeof(TO)) {
+            const u32x4 v = *(const u32x4*)(x + e0);
+            ET<TI>::unpack(v, f);
+        } else {                                   // fp32 in, bf16 out: 2 x 16-byte loads
+            const u32x4 v0 = *(const u32x4*)(x + e0), v1 = *(const u32x4*)(x + e0 + 4);
+            ET<float>::unpack(v0, f); ET<float>::unpack(v1, f + 4);
+        }
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             const int c = c0 + e, g = c / cpg;
@@ -109,18 +116,19 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, const float* __restrict
             if (swish) t = t / (1.f + expf(-t));
             f[e] = t;
         }
-        *(u32x4*)(y + e0) = ET<T>::pack(f);
+        *(u32x4*)(y + e0) = ET<TO>::pack(f);
     }
 }
-template <typename T>
-void launch_gn_apply(hipStream_t s, const T* x, const float* stats, const float* gamma, const float* beta,
-                     T* y, int B, int HW, int C, int swish) {
-    const long total_vec = (long)B * HW * C / ET<T>::EPV;
+template <typename TI, typename TO>
+void launch_gn_apply(hipStream_t s, const TI* x, const float* stats, const float* gamma, const float* beta,
+                     TO* y, int B, int HW, int C, int swish) {
+    const long total_vec = (long)B * HW * C / ET<TO>::EPV;
     const int blocks = (int)((total_vec + 255) / 256 < 8192 ? (total_vec + 255) / 256 : 8192);
-    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, y, (long)HW * C, C, swish, total_vec);
+    hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, y, (long)HW * C, C, swish, total_vec);
 }
-template void launch_gn_apply<float>(hipStream_t, const float*, const float*, const float*, const float*, float*, int, int, int, int);
-template void launch_gn_apply<bf16>(hipStream_t, const bf16*, const float*, const float*, const float*, bf16*, int, int, int, int);
+template void launch_gn_apply<float, float>(hipStream_t, const float*, const float*, const float*, const float*, float*, int, int, int, int);
+template void launch_gn_apply<float, bf16>(hipStream_t, const float*, const float*, const float*, const float*, bf16*, int, int, int, int);
+template void launch_gn_apply<bf16, bf16>(hipStream_t, const bf16*, const float*, const float*, const float*, bf16*, int, int, int, int);
 
 // ------------------------------------------------------------------------------- row softmax
 template <typename T>

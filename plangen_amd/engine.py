@@ -395,11 +395,11 @@ class Engine:
         return out
 
     def op_groupnorm(self, x_nhwc: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, swish: bool) -> torch.Tensor:
-        x = self._dev(x_nhwc, self.tdtype)
+        x = self._dev(x_nhwc, torch.float32)          # the VQ skip stream is fp32 in both modes
         B, Hs, Ws, Cc = x.shape
         g = self._dev(gamma, torch.float32)
         b = self._dev(beta, torch.float32)
-        out = torch.empty_like(x)
+        out = torch.empty(x.shape, dtype=self.tdtype, device=self.device)
         self._check(self.lib.pg_op_groupnorm(self.h, self._p(x), self._p(g), self._p(b), self._p(out), B, Hs * Ws, Cc,
                                              int(swish), self.stream), "pg_op_groupnorm")
         torch.cuda.synchronize()
