@@ -366,8 +366,11 @@ int pg_engine::create() {
         const long rows = cfg.max_rows;
         long need = 0;
         auto upd = [&](long N, long K) {
-            long S = (K % 128 == 0) ? skinny_pick_splits((int)N, (int)K) : 1;
-            if (S * rows * N > need) need = S * rows * N;
+            for (long mc : {16L, 32L, 64L, 128L, rows}) {
+                const long m = mc < rows ? mc : rows;
+                const long S = (K % 128 == 0) ? skinny_pick_splits((int)N, (int)K, (int)m) : 1;
+                if (S * m * N > need) need = S * m * N;
+            }
         };
         upd(3L * HDm, Hh); upd(Hh, HDm); upd(2L * I, Hh); upd(Hh, I); upd(G, Hh); upd(V, G);
         if (cfg.with_lm_head) upd(cfg.vocab, Hh);
@@ -528,7 +531,7 @@ void pg_engine::gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, in
     slab_last = (long)M * N;
     if constexpr (std::is_same<T, bf16>::value) {
         if (allow_skinny && M <= 512 && K % 128 == 0) {
-            const int S = skinny_pick_splits(N, K);
+            const int S = skinny_pick_splits(N, K, M);
             if ((long)S * M * N <= part_elems) {
                 launch_gemm_skinny(s, a, W, part, M, N, K, S);
                 S_last = S;
@@ -570,8 +573,16 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
         }
         gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk);
         launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);
-        gemm_llm<T>(s, (const T*)xn, (const T*)ly.wgu, M, 2 * I, Hh, sk);
-        launch_silu_mul<T>(s, part, S_last, slab_last, (T*)hbuf, M, I);
+        bool fused = false;
+        if constexpr (std::is_same<T, bf16>::value) {
+            // decode: SwiGLU gate fused into the gate|up GEMM epilogue (S = 1, no slab, no extra kernel)
+            if (sk && M <= 512 && Hh % 128 == 0 && skinny_pick_splits(2 * I, Hh, M) == 1)
+                fused = launch_gemm_skinny_swiglu(s, (const bf16*)xn, (const bf16*)ly.wgu, (bf16*)hbuf, M, 2 * I, Hh);
+        }
+        if (!fused) {
+            gemm_llm<T>(s, (const T*)xn, (const T*)ly.wgu, M, 2 * I, Hh, sk);
+            launch_silu_mul<T>(s, part, S_last, slab_last, (T*)hbuf, M, I);
+        }
         gemm_llm<T>(s, (const T*)hbuf, (const T*)ly.wd, M, Hh, I, sk);
         S_pend = S_last; slab_pend = slab_last;
     }
@@ -1071,7 +1082,7 @@ int pg_op_gemm(pg_handle h, const void* a_dev, const void* w_dev, float* out_dev
     (void)hipSetDevice(h->dev);
     int S = 1;
     if (h->bf && (force_kind == 1 || (force_kind == 0 && M <= 128)) && K % 128 == 0) {
-        S = skinny_pick_splits(N, K);
+        S = skinny_pick_splits(N, K, M);
         launch_gemm_skinny((hipStream_t)s, (const bf16*)a_dev, (const bf16*)w_dev, out_dev, M, N, K, S);
     } else {
         GemmA ga; ga.ptr = a_dev; ga.lda = K;

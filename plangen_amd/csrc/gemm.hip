@@ -299,17 +299,113 @@ template void launch_gemm<bf16>(hipStream_t, const GemmA&, const bf16*, long, lo
 
 // ------------------------------------------------------------------------------- skinny GEMM
 #define SK_BK 128
-#define SK_ROWB 272           // LDS row stride (256 B of k + 16 B pad: conflict-free ds_read_b128)
+#define SK_ROWB 288           // LDS row stride (256 B of k + 32 B pad: conflict-free ds_read_b128 for the (lr, g) fragment order)
+
+
+// Block epilogue of the skinny kernels: the 4 waves' accumulators (MFMA C layout: lane holds
+// 4 rows x 1 column) are transposed through LDS so every lane stores 16 contiguous bytes
+// (16 lanes = one 256-byte output row segment) instead of 32 scattered dword stores.
+// smem must hold MT*16 rows x (64+4) floats and be free (call after the loop's last barrier).
+template <int MT>
+__device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)[MT], float* __restrict__ o, int M, int N,
+                                                  int mbase, int nbase, int w, int g, int lr, int tid) {
+    constexpr int LD = 68;
+    float* t = (float*)smem;
+    __syncthreads();                                   // every wave is done reading the x tiles
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[(mt * 16 + g * 4 + r) * LD + w * 16 + lr] = acc[mt][r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int v = tid + j * 256, row = v >> 4, c4 = (v & 15) * 4;
+        const int m = mbase + row, n = nbase + c4;
+        if (m < M && n < N) *(f32x4*)(o + (long)m * N + n) = *(const f32x4*)(t + row * LD + c4);
+    }
+}
+
+// SwiGLU epilogue (S == 1 only): the block's 64 columns are 2 x [16 gate | 16 up] (weights
+// interleaved in blocks of 16 at load time), so h = silu(g) * u for 32 output columns comes
+// straight out of the transposed LDS tile; bf16 h [M, I] is written, no fp32 slab, no extra kernel.
+template <int MT>
+__device__ __forceinline__ void skinny_store_swiglu(char* smem, const f32x4 (&acc)[MT], bf16* __restrict__ h, int M, int I,
+                                                    int mbase, int nblk, int w, int g, int lr, int tid) {
+    constexpr int LD = 68;
+    float* t = (float*)smem;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[(mt * 16 + g * 4 + r) * LD + w * 16 + lr] = acc[mt][r];
+    __syncthreads();
+    // MT*16 rows x 32 outputs = MT*512 values; thread -> 2 adjacent outputs per pass
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int v = tid + j * 256, row = v >> 4, c2 = (v & 15) * 2;        // c2 in [0,32)
+        const int m = mbase + row, col = nblk * 32 + c2;
+        if (m < M && col < I) {
+            const int tc = (c2 >> 4) * 32 + (c2 & 15);                        // gate column in the tile
+            const float g0 = t[row * LD + tc], g1 = t[row * LD + tc + 1];
+            const float u0 = t[row * LD + tc + 16], u1 = t[row * LD + tc + 17];
+            const float h0 = (g0 / (1.f + expf(-g0))) * u0, h1 = (g1 / (1.f + expf(-g1))) * u1;
+            *(uint32_t*)(h + (long)m * I + col) = pack_bf16x2(h0, h1);
+        }
+    }
+}
+
+// MFMA phase of one 128-wide K chunk: A fragments (x tile in LDS, row stride SK_ROWB) are read
+// one m-tile PAIR ahead of the MFMAs that consume them (double-buffered registers), and the
+// two m-tiles of a pair alternate accumulators so no MFMA waits on the previous one's result.
+// Without this hipcc serialises ds_read -> s_waitcnt lgkmcnt(0) -> mfma through one fragment
+// register (measured ~80 clk per MFMA per SIMD instead of ~17).
+template <int MT>
+__device__ __forceinline__ void skinny_mfma_chunk(const char* xt, int lr, int g, const bf16x8 (&wc)[4], f32x4 (&acc)[MT]) {
+    const char* rp = xt + lr * SK_ROWB + g * 16;
+    if constexpr (MT == 1) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(rp + i * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], wc[i], acc[0], 0, 0, 0);
+    } else {
+        constexpr int NP = MT / 2;
+        bf16x8 af[2][2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[0][h][i] = *(const bf16x8*)(rp + h * 16 * SK_ROWB + i * 64);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p + 1 < NP) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        af[(p + 1) & 1][h][i] = *(const bf16x8*)(rp + ((p + 1) * 2 + h) * 16 * SK_ROWB + i * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the next pair's 8 reads ahead of this pair's MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p & 1][0][i], wc[i], acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p & 1][1][i], wc[i], acc[2 * p + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
 
 template <int MT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
                                                          float* __restrict__ out, int M, int N, int K, int nck) {
     extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 * MT*16*SK_ROWB
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
     const int split = blockIdx.y, mblk = blockIdx.z;
     const int mbase = mblk * 128;
     const int n = blockIdx.x * 64 + w * 16 + lr;
-    const bf16* wp = W + (long)(n < N ? n : N - 1) * K + g * 32;
+    // fragment order: k-step i, lane (lr, g) holds k = i*32 + g*8 .. +8, so the 4 lanes of a W row
+    // read one full 64-byte sector per load instruction
+    const bf16* wp = W + (long)(n < N ? n : N - 1) * K + g * 8;
     const int kbeg = split * nck * SK_BK;
     constexpr int XB = MT * 16 * SK_ROWB;
 
@@ -333,7 +429,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
     bf16x8 wc[4], wn[4];
     auto wload = [&](bf16x8* dst, int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(wp + k0 + i * 8);
+        for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(wp + k0 + i * 32);
     };
     f32x4 acc[MT];
 #pragma unroll
@@ -348,15 +444,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
         const bool more = c + 1 < nck;
         if (more) { wload(wn, knext); xload(knext); }
         const char* xt = smem + (c & 1) * XB;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const char* rp = xt + (mt * 16 + lr) * SK_ROWB + g * 64;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8 a = *(const bf16x8*)(rp + i * 16);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wc[i], acc[mt], 0, 0, 0);
-            }
-        }
+        skinny_mfma_chunk<MT>(xt, lr, g, wc, acc);
         if (more) {
             xstore((c + 1) & 1);
 #pragma unroll
@@ -364,30 +452,29 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16* __restrict
         }
         __syncthreads();
     }
-    if (n < N) {
-        float* o = out + (long)split * M * N;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mbase + mt * 16 + g * 4 + r;
-                if (m < M) o[(long)m * N + n] = acc[mt][r];
-            }
-    }
+    skinny_store_tile<MT>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid);
 }
 
-int skinny_pick_splits(int N, int K) {
+// Split-K count: smallest divisor S of the chunk count that gives enough blocks to keep the
+// 256 CUs streaming.  Measured on MI355X (tools/skinny_sweep.py): at M = 128 fewer, fatter
+// blocks win (slab traffic grows with S), at M <= 32 more, thinner ones do; S is restricted to
+// chunk counts the unrolled kernel is instantiated for.
+int skinny_pick_splits(int N, int K, int M) {
     const int nblk = (N + 63) / 64, nchunks = K / SK_BK;
+    const int target = M >= 96 ? 160 : (M >= 48 ? 256 : 512);
     int best = 1;
     for (int S = 1; S <= nchunks; ++S) {
         if (nchunks % S) continue;
+        const int nck = nchunks / S;
+        if (!(nck == 1 || nck == 2 || nck == 4 || nck == 8 || nck == 11 || nck == 16 || nck == 22) && S != nchunks) continue;
         best = S;
-        if (nblk * S >= 256) break;
+        if (nblk * S >= target) break;
     }
     return best;
 }
+int skinny_pick_splits(int N, int K) { return skinny_pick_splits(N, K, 128); }
 
-void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
     if (M <= 0) return;
     const int nck = K / SK_BK / S;
     const int mblocks = (M + 127) / 128;
@@ -405,4 +492,143 @@ void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out,
         if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * SK_ROWB); attr = true; }
         hipLaunchKernelGGL(kfn, grid, block, 2 * 8 * 16 * SK_ROWB, s, x, W, out, M, N, K, nck);
     }
+}
+
+// ------------------------------------------------------------------------------- skinny GEMM v3
+// Same geometry as v1 (BN = 64: 4 waves x 16 columns, BK = 128) but the W stream is decoupled
+// from the per-chunk barrier: a register ring of depth D keeps D chunks of every wave's W
+// rows in flight (the HBM requests of chunk c+D are issued while chunk c computes), the chunk
+// loop is fully unrolled (NCK = chunks per block, compile time) so the ring is statically
+// indexed.  XDB: x tile double-buffered (2 blocks/CU at MT=8) or single-buffered (4 blocks/CU).
+template <int MT, int NCK, int D, bool XDB, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+                                                          float* __restrict__ out, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XB = MT * 16 * SK_ROWB;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
+    const int split = blockIdx.y, mbase = blockIdx.z * 128;
+    const int n = blockIdx.x * 64 + w * 16 + lr;
+    const int kbeg = split * NCK * SK_BK;
+    const bf16* wp = W + (long)(n < N ? n : N - 1) * K + kbeg + g * 8;
+    const bf16* xp = x + kbeg;
+
+    u32x4 xs[MT];
+    auto xload = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + j * 256, row = v >> 4, cv = v & 15;
+            const int m = mbase + row;
+            if (m < M) xs[j] = *(const u32x4*)(xp + (long)m * K + c * SK_BK + cv * 8);
+            else xs[j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto xstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + j * 256, row = v >> 4, cv = v & 15;
+            *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
+        }
+    };
+    bf16x8 wr[D][4];
+#pragma unroll
+    for (int c = 0; c < D && c < NCK; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[c][i] = *(const bf16x8*)(wp + c * SK_BK + i * 32);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    xload(0);
+    xstore(0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+        if (c + 1 < NCK) xload(c + 1);
+        const char* xt = smem + (XDB ? (c & 1) * XB : 0);
+        skinny_mfma_chunk<MT>(xt, lr, g, wr[c % D], acc);
+        if (c + D < NCK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wr[c % D][i] = *(const bf16x8*)(wp + (c + D) * SK_BK + i * 32);
+        }
+        if (c + 1 < NCK) {
+            if (!XDB) __syncthreads();
+            xstore(XDB ? ((c + 1) & 1) : 0);
+            __syncthreads();
+        }
+    }
+    if constexpr (EPI == 1) skinny_store_swiglu<MT>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid);
+    else skinny_store_tile<MT>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid);
+}
+template <int MT, int NCK, int D, bool XDB, int EPI = 0>
+static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+    constexpr int LDS = (XDB ? 2 : 1) * MT * 16 * SK_ROWB;
+    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+    dim3 grid((N + 63) / 64, S, (M + 127) / 128), block(256);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K);
+}
+template <int D, bool XDB>
+static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+    const int nck = K / SK_BK / S;
+    if (nck * S * SK_BK != K) return 0;
+    switch (nck) {
+        case 1: launch_sk3<8, 1, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 2: launch_sk3<8, 2, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 4: launch_sk3<8, 4, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 8: launch_sk3<8, 8, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 11: launch_sk3<8, 11, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 16: launch_sk3<8, 16, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 22: launch_sk3<8, 22, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        default: return 0;
+    }
+}
+
+
+// ---- production dispatch: v3 (W register ring depth 2, double-buffered x tile) ----
+template <int MT, int EPI>
+static bool sk3_prod_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck) {
+    switch (nck) {
+        case 1: launch_sk3<MT, 1, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
+        case 2: launch_sk3<MT, 2, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
+        case 4: launch_sk3<MT, 4, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
+        case 8: launch_sk3<MT, 8, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
+        case 11: launch_sk3<MT, 11, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
+        case 16: launch_sk3<MT, 16, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
+        case 22: launch_sk3<MT, 22, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
+        default: return false;
+    }
+}
+template <int EPI>
+static bool sk3_prod(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+    const int nck = K / SK_BK / S;
+    if (nck * S * SK_BK != K) return false;
+    const int mrows = M < 128 ? M : 128;
+    if (mrows <= 16) return sk3_prod_nck<1, EPI>(s, x, W, out, M, N, K, S, nck);
+    if (mrows <= 32) return sk3_prod_nck<2, EPI>(s, x, W, out, M, N, K, S, nck);
+    if (mrows <= 64) return sk3_prod_nck<4, EPI>(s, x, W, out, M, N, K, S, nck);
+    return sk3_prod_nck<8, EPI>(s, x, W, out, M, N, K, S, nck);
+}
+
+void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
+// variant table for the microbenchmark (tools/skinny_sweep.py): returns BK (0 = unsupported)
+int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+    switch (variant) {
+        case 0: launch_gemm_skinny(s, x, W, out, M, N, K, S); return 128;                  // production (v3, falls back to v1)
+        case 1: launch_gemm_skinny_v1(s, x, W, out, M, N, K, S); return 128;               // v1: 1-deep prefetch
+        case 20: return sk3_dispatch<2, true>(s, x, W, out, M, N, K, S) ? 128 : 0;         // v3 ring 2, x double-buffered
+        case 21: return sk3_dispatch<3, true>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 23: return sk3_dispatch<2, false>(s, x, W, out, M, N, K, S) ? 128 : 0;        // x single-buffered
+        default: return 0;
+    }
+}
+
+void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+    if (M <= 0) return;
+    if (!sk3_prod<0>(s, x, W, out, M, N, K, S)) launch_gemm_skinny_v1(s, x, W, out, M, N, K, S);
+}
+// gate|up GEMM with the SwiGLU gate fused (S = 1): h bf16 [M, N/2].  Returns false when the
+// shape has no fused instantiation (caller falls back to slabs + silu_mul kernel).
+bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K) {
+    if (M <= 0) return true;
+    return sk3_prod<1>(s, x, W, (float*)h, M, N, K, 1);
 }

@@ -40,7 +40,10 @@ void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strid
 // W [N,K] bf16, out fp32 [S,M,N] split-K partial slabs (consumer kernels reduce over S).
 // Returns S.  N % 16 == 0, K % 128 == 0.
 int skinny_pick_splits(int N, int K);
+int skinny_pick_splits(int N, int K, int M);
+bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K);
 void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
+int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
 
 // ---------------------------------------------------------------- LLM elementwise / attention
 // x (fp32 residual stream, in/out) += sum_s partial[s];  xn = w * (x * rsqrt(mean(x^2)+eps)).

@@ -116,3 +116,30 @@ def test_decode_step_consistent_with_prefill():
     full = torch.cat([emb, nxt[:, None, :]], dim=1)
     h_full = e.prefill_embeds(full, [0, 0], return_hidden=True)[:, -1].cpu()
     assert (h_step - h_full).abs().max() < 0.06 * h_full.abs().max()
+
+
+def test_large_batch_decode_path_matches_small_batch_path():
+    """At R >= 96 rows the decode GEMMs switch geometry (fewer split-K slabs, SwiGLU gate fused
+    into the gate|up GEMM epilogue).  128 rows that are 64 copies of one CFG pair must all agree
+    bit-for-bit with each other and, within fp32-summation-order tolerance, with the 2-row run."""
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    cfg = PlanGenConfig.janus_pro_1b()
+    e = Engine(cfg, dtype="bf16", max_rows=128, max_prompt=32, max_new=8, max_images=1)
+    e.init_synthetic(seed=0)
+    g = torch.Generator().manual_seed(4)
+    L = 24
+    pair = torch.randint(10, 100000, (2, L), generator=g).int()
+    nxt = (torch.randn(2, cfg.hidden, generator=g) * 0.02)
+    outs = {}
+    for reps in (1, 64):
+        ids = pair.repeat(reps, 1)
+        e.prefill(ids, [0] * (2 * reps))
+        h = e.step(nxt.repeat(reps, 1)).cpu()
+        h2 = e.step(nxt.repeat(reps, 1)).cpu()
+        outs[reps] = (h, h2)
+    for k in (0, 1):
+        big, small = outs[64][k], outs[1][k]
+        assert torch.equal(big[0::2], big[0:1].expand(64, -1)) and torch.equal(big[1::2], big[1:2].expand(64, -1))
+        assert (big[:2] - small).abs().max() < 0.02 * small.abs().max()
+    e.close()
