@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=value (pg_set_option)")
     args = ap.parse_args()
 
     import torch
@@ -117,6 +118,9 @@ def main():
     T = args.tokens or cfg.img_tokens
     eng = Engine(cfg, dtype=args.dtype, max_rows=2 * B, max_prompt=L, max_new=cfg.img_tokens, max_images=B, device=local)
     eng.init_synthetic(seed=0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
 
     # rank 0 collates the global batch (B images per rank) and broadcasts it over RCCL
     if rank == 0:

@@ -103,7 +103,7 @@ struct pg_engine {
     hipStream_t istream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr, ev_v0 = nullptr, ev_v1 = nullptr;
     hipGraphExec_t gexec = nullptr; std::vector<int64_t> gkey;
-    bool use_graph = true; bool time_attn = false;
+    bool use_graph = true; bool time_attn = false; bool fuse_rope = true;
     std::vector<hipEvent_t> attn_ev; size_t attn_ev_used = 0; std::vector<double> attn_ev_bytes;
     pg_timing timing{};
     bool have_decode_t = false, have_prefill_t = false, have_vq_t = false;
@@ -559,11 +559,17 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
         const Layer& ly = layers[li];
         launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);
         gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk);
-        launch_rope_kv<T>(s, part, S_last, slab_last, (T*)qbuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), mode, M,
-                          cfg.n_heads, slots, max_pos);
         const bool timed = time_attn && mode == 0 && attn_ev_used + 2 <= attn_ev.size();
-        if (timed) (void)hipEventRecord(attn_ev[attn_ev_used], s);
-        launch_attn<T>(s, (const T*)qbuf, (T*)obuf, (const T*)kc(li), (const T*)vc(li), seq(), mode, M, cfg.n_heads, slots, scale);
+        if (mode == 0 && fuse_rope) {
+            if (timed) (void)hipEventRecord(attn_ev[attn_ev_used], s);
+            launch_attn_decode_fused<T>(s, part, S_last, slab_last, (T*)obuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), M,
+                                        cfg.n_heads, slots, max_pos, scale);
+        } else {
+            launch_rope_kv<T>(s, part, S_last, slab_last, (T*)qbuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), mode, M,
+                              cfg.n_heads, slots, max_pos);
+            if (timed) (void)hipEventRecord(attn_ev[attn_ev_used], s);
+            launch_attn<T>(s, (const T*)qbuf, (T*)obuf, (const T*)kc(li), (const T*)vc(li), seq(), mode, M, cfg.n_heads, slots, scale);
+        }
         if (timed) {
             (void)hipEventRecord(attn_ev[attn_ev_used + 1], s);
             double keys = 0;
@@ -1043,6 +1049,8 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!h || !key) return PG_ERR_ARG;
     if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
     if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
+    if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
+    if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     h->err = std::string("unknown option ") + key;
     return PG_ERR_ARG;
 }

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16* __restr
 // chunk counts the unrolled kernel is instantiated for.
 int skinny_pick_splits(int N, int K, int M) {
     const int nblk = (N + 63) / 64, nchunks = K / SK_BK;
-    const int target = M >= 96 ? 160 : (M >= 48 ? 256 : 512);
+    const int target = M >= 96 ? 128 : (M >= 48 ? 256 : 512);   // GEMM+consumer optimum (sweep "+n" columns)
     int best = 1;
     for (int S = 1; S <= nchunks; ++S) {
         if (nchunks % S) continue;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny3_kernel(const bf16* __rest
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XB = MT * 16 * SK_ROWB;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
-    const int split = blockIdx.y, mbase = blockIdx.z * 128;
+    const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
     const int n = blockIdx.x * 64 + w * 16 + lr;
     const int kbeg = split * NCK * SK_BK;
     const bf16* wp = W + (long)(n < N ? n : N - 1) * K + kbeg + g * 8;
@@ -564,7 +564,7 @@ static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, 
     auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-    dim3 grid((N + 63) / 64, S, (M + 127) / 128), block(256);
+    dim3 grid((N + 63) / 64, S, (M + MT * 16 - 1) / (MT * 16)), block(256);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K);
 }
 template <int D, bool XDB>
@@ -606,6 +606,10 @@ static bool sk3_prod(hipStream_t s, const bf16* x, const bf16* W, float* out, in
     if (mrows <= 16) return sk3_prod_nck<1, EPI>(s, x, W, out, M, N, K, S, nck);
     if (mrows <= 32) return sk3_prod_nck<2, EPI>(s, x, W, out, M, N, K, S, nck);
     if (mrows <= 64) return sk3_prod_nck<4, EPI>(s, x, W, out, M, N, K, S, nck);
+    // narrow outputs (N = 2048: o_proj, down_proj): too few column blocks to fill 256 CUs, so the
+    // rows are split into 64-row blocks as well (the second reader of a W slab hits L2);
+    // measured 8.0 -> 6.7 us (o) and 15.3 -> 12.4 us (down) at M = 128, slower for wide N.
+    if ((N + 63) / 64 < 64 && EPI == 0) return sk3_prod_nck<4, EPI>(s, x, W, out, M, N, K, S, nck);
     return sk3_prod_nck<8, EPI>(s, x, W, out, M, N, K, S, nck);
 }
 
@@ -618,6 +622,8 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 20: return sk3_dispatch<2, true>(s, x, W, out, M, N, K, S) ? 128 : 0;         // v3 ring 2, x double-buffered
         case 21: return sk3_dispatch<3, true>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 23: return sk3_dispatch<2, false>(s, x, W, out, M, N, K, S) ? 128 : 0;        // x single-buffered
+        case 24: return sk3_prod_nck<4, 0>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // 64-row M blocks (grid.z = M/64)
+        case 25: return sk3_prod_nck<2, 0>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // 32-row M blocks
         default: return 0;
     }
 }

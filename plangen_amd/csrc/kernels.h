@@ -82,6 +82,11 @@ void launch_rope_kv(hipStream_t s, const float* qkv, int S, long slab, T* qbuf, 
 template <typename T>
 void launch_attn(hipStream_t s, const T* qbuf, T* obuf, const T* kc, const T* vc, SeqState st, int mode,
                  int M, int nh, int slots, float scale);
+// decode step: RoPE + KV append + attention in one kernel (reads the QKV split-K slabs)
+template <typename T>
+void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc,
+                              const float* cos_t, const float* sin_t, SeqState st, int M, int nh, int slots,
+                              int max_pos, float scale);
 // h = silu(g) * u from gate-up partial fp32 [S, M, 2I] whose columns are interleaved in
 // blocks of 16 (16 gate, 16 up, ...)
 template <typename T>

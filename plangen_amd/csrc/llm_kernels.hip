@@ -161,7 +161,7 @@ template void launch_rope_kv<bf16>(hipStream_t, const float*, int, long, bf16*, 
 // KPI = 64/LPK keys (bf16: 4 keys, fp32: 2).  Every LPK-lane group runs its OWN online
 // softmax over the keys it sees (no cross-lane max exchange inside the loop); the
 // 4 waves x KPI groups partial states (m, l, o[128]) are merged once through LDS.
-template <typename T, int UN>
+template <typename T, int UN, bool NT>
 __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qbuf, T* __restrict__ obuf,
                                                   const T* __restrict__ kc, const T* __restrict__ vc,
                                                   SeqState st, int mode, int nh, int slots, float scale) {
@@ -196,13 +196,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qbuf, T
         for (int u = 0; u < UN; ++u) {
             int key = base + u * KPI + grp;
             key = key < klen ? key : klen - 1;             // clamp: load stays in bounds
-            kv[u] = *(const u32x4*)(kb + (long)key * 128);
+            kv[u] = NT ? __builtin_nontemporal_load((const u32x4*)(kb + (long)key * 128)) : *(const u32x4*)(kb + (long)key * 128);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             int key = base + u * KPI + grp;
             key = key < klen ? key : klen - 1;
-            vv[u] = *(const u32x4*)(vb + (long)key * 128);
+            vv[u] = NT ? __builtin_nontemporal_load((const u32x4*)(vb + (long)key * 128)) : *(const u32x4*)(vb + (long)key * 128);
         }
         float sc[UN];
 #pragma unroll
@@ -253,11 +253,157 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qbuf, T
         ET<T>::st(obuf + (long)qi * HD + head * 128 + tid, num / den);
     }
 }
+// ------------------------------------------------------------------------------- fused decode attention
+// Decode step only: one block per (row, head) does RoPE(q), RoPE(k), appends K/V at slot
+// len+n_dec (reading the QKV GEMM's fp32 split-K slabs directly), then streams that row-head's
+// cached K/V (non-temporal 16-byte loads: the cache is read exactly once per step) and merges
+// the new key, which never leaves LDS, as one more online-softmax state.  Replaces
+// rope_kv_kernel + attn_kernel (one launch and the q round trip less per layer).
+template <typename T, int UN>
+__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const float* __restrict__ qkv, int S, long slab,
+                                                               T* __restrict__ obuf, T* __restrict__ kc, T* __restrict__ vc,
+                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                               SeqState st, int nh, int slots, int max_pos, float scale) {
+    constexpr int EPV = ET<T>::EPV, LPK = 128 / EPV, KPI = 64 / LPK, NST = 4 * KPI;
+    __shared__ float s_o[NST][128];
+    __shared__ float s_m[NST], s_l[NST];
+    __shared__ __attribute__((aligned(16))) float s_q[128];
+    __shared__ float s_k[128], s_v[128];
+    __shared__ float s_new;
+    const int row = blockIdx.x, head = blockIdx.y;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int grp = l / LPK, lk = l % LPK;
+    const int slot = st.len[row] + *st.n_dec;             // where the new key goes
+    int nprev = slot < slots ? slot : slots - 1;          // cached keys to stream (capacity guard)
+    const int HD = nh * 128;
+    const long cbase = ((long)row * nh + head) * slots * 128;
+    if (tid < 64) {
+        const int j = tid;
+        int pos = st.pos_off[row] + slot;
+        if (pos >= max_pos) pos = max_pos - 1;
+        const long base = (long)row * 3 * HD + head * 128 + j;
+        float q0 = 0, q1 = 0, k0 = 0, k1 = 0, v0 = 0, v1 = 0;
+        for (int s = 0; s < S; ++s) {
+            const float* p = qkv + (long)s * slab + base;
+            q0 += p[0]; q1 += p[64]; k0 += p[HD]; k1 += p[HD + 64]; v0 += p[2 * HD]; v1 += p[2 * HD + 64];
+        }
+        const float c = cos_t[(long)pos * 64 + j], sn = sin_t[(long)pos * 64 + j];
+        // the query is rounded to T exactly like the unfused path (qbuf was T), then pre-scaled
+        s_q[j] = ET<T>::round(q0 * c - q1 * sn) * scale;
+        s_q[j + 64] = ET<T>::round(q1 * c + q0 * sn) * scale;
+        const float kr0 = ET<T>::round(k0 * c - k1 * sn), kr1 = ET<T>::round(k1 * c + k0 * sn);
+        const float vr0 = ET<T>::round(v0), vr1 = ET<T>::round(v1);
+        s_k[j] = kr0; s_k[j + 64] = kr1; s_v[j] = vr0; s_v[j + 64] = vr1;
+        if (slot < slots) {
+            const long co = cbase + (long)slot * 128 + j;
+            ET<T>::st(kc + co, kr0); ET<T>::st(kc + co + 64, kr1);
+            ET<T>::st(vc + co, vr0); ET<T>::st(vc + co + 64, vr1);
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        float d = s_q[l] * s_k[l] + s_q[l + 64] * s_k[l + 64];
+        d = wave_sum(d);
+        if (l == 0) s_new = d;
+    }
+    float q[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) q[e] = s_q[lk * EPV + e];
+    const T* kb = kc + cbase + lk * EPV;
+    const T* vb = vc + cbase + lk * EPV;
+    float m_run = -INFINITY, l_run = 0.f, o[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) o[e] = 0.f;
+    constexpr int KPW = KPI * UN;
+    for (int base = w * KPW; base < nprev; base += 4 * KPW) {
+        u32x4 kv[UN], vv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int key = base + u * KPI + grp;
+            key = key < nprev ? key : nprev - 1;
+            kv[u] = __builtin_nontemporal_load((const u32x4*)(kb + (long)key * 128));
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int key = base + u * KPI + grp;
+            key = key < nprev ? key : nprev - 1;
+            vv[u] = __builtin_nontemporal_load((const u32x4*)(vb + (long)key * 128));
+        }
+        float sc[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float kf[EPV]; ET<T>::unpack(kv[u], kf);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) d = fmaf(q[e], kf[e], d);
+#pragma unroll
+            for (int o_ = LPK / 2; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
+            sc[u] = (base + u * KPI + grp < nprev) ? d : -INFINITY;
+        }
+        float mx = m_run;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) mx = fmaxf(mx, sc[u]);
+        if (mx > -INFINITY) {
+            const float alpha = __expf(m_run - mx);
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) o[e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float p = __expf(sc[u] - mx);
+                l_run += p;
+                float vf[EPV]; ET<T>::unpack(vv[u], vf);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o[e] = fmaf(p, vf[e], o[e]);
+            }
+            m_run = mx;
+        }
+    }
+    const int stt = w * KPI + grp;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) s_o[stt][lk * EPV + e] = o[e];
+    if (lk == 0) { s_m[stt] = m_run; s_l[stt] = l_run; }
+    __syncthreads();
+    if (tid < 128) {
+        float Mx = s_new;                                   // the new key is always a valid state
+#pragma unroll
+        for (int i = 0; i < NST; ++i) Mx = fmaxf(Mx, s_m[i]);
+        const float fn = __expf(s_new - Mx);
+        float num = fn * s_v[tid], den = fn;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const float f = (s_m[i] > -INFINITY) ? __expf(s_m[i] - Mx) : 0.f;
+            num = fmaf(f, s_o[i][tid], num);
+            den = fmaf(f, s_l[i], den);
+        }
+        ET<T>::st(obuf + (long)row * HD + head * 128 + tid, num / den);
+    }
+}
+template <typename T>
+void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc,
+                              const float* cos_t, const float* sin_t, SeqState st, int M, int nh, int slots,
+                              int max_pos, float scale) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8>), dim3(M, nh), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
+                       st, nh, slots, max_pos, scale);
+}
+template void launch_attn_decode_fused<float>(hipStream_t, const float*, int, long, float*, float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
+template void launch_attn_decode_fused<bf16>(hipStream_t, const float*, int, long, bf16*, bf16*, bf16*, const float*, const float*, SeqState, int, int, int, int, float);
+
+int g_attn_variant = -1;      // tuning knob (pg_set_option "attn_variant"); -1: nt loads for decode, plain for prefill
 template <typename T>
 void launch_attn(hipStream_t s, const T* qbuf, T* obuf, const T* kc, const T* vc, SeqState st, int mode,
                  int M, int nh, int slots, float scale) {
     if (M <= 0) return;
-    hipLaunchKernelGGL((attn_kernel<T, 8>), dim3(M, nh), dim3(256), 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale);
+    dim3 grid(M, nh), block(256);
+    const int variant = g_attn_variant >= 0 ? g_attn_variant : (mode == 0 ? 1 : 0);
+    switch (variant) {
+        case 1: hipLaunchKernelGGL((attn_kernel<T, 8, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
+        case 2: hipLaunchKernelGGL((attn_kernel<T, 4, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
+        case 3: hipLaunchKernelGGL((attn_kernel<T, 4, false>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
+        case 4: hipLaunchKernelGGL((attn_kernel<T, 16, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
+        default: hipLaunchKernelGGL((attn_kernel<T, 8, false>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
+    }
 }
 template void launch_attn<float>(hipStream_t, const float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
 template void launch_attn<bf16>(hipStream_t, const bf16*, bf16*, const bf16*, const bf16*, SeqState, int, int, int, int, float);
