@@ -87,6 +87,7 @@ struct pg_engine {
     int32_t *d_len = nullptr, *d_pos_off = nullptr, *d_ndec = nullptr, *d_tok_row = nullptr, *d_tok_j = nullptr,
             *d_tok_src = nullptr, *d_last = nullptr, *d_unf = nullptr, *d_anyunf = nullptr;
     int32_t* h_stage = nullptr;                                  // pinned host staging
+    float* cfg_pv = nullptr; int* cfg_pi = nullptr;              // sampler stage-1 winners
     void* kv = nullptr;
     // ---- workspaces
     long max_tok = 0;
@@ -123,7 +124,8 @@ struct pg_engine {
     size_t kv_layer_elems() const { return (size_t)cfg.max_rows * cfg.n_heads * slots * 128; }
     void* kc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 0) * kv_layer_elems() * esz; }
     void* vc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 1) * kv_layer_elems() * esz; }
-    SeqState seq() const { return SeqState{d_len, d_pos_off, d_ndec, d_tok_row, d_tok_j}; }
+    int shared_len = 0, shared_row = 1; bool share_uncond = true;
+    SeqState seq() const { return SeqState{d_len, d_pos_off, d_ndec, d_tok_row, d_tok_j, shared_len, shared_row}; }
 
     int create();
     void add_slot(const std::string& name, void* dst, SlotKind k, long n, int a = 0, int b = 0, int c = 0);
@@ -353,6 +355,8 @@ int pg_engine::create() {
     TRY(dalloc(&d_unf, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_anyunf, 1024 * 4));
     TRY(dalloc(&d_ndec, 64));
+    TRY(dalloc(&cfg_pv, (size_t)cfg.max_rows * 16 * 4));
+    TRY(dalloc(&cfg_pi, (size_t)cfg.max_rows * 16 * 4));
     HIPCHK(hipMemset(d_ndec, 0, 64));
     TRY(dalloc(&d_tok_row, (size_t)max_tok * 4));
     TRY(dalloc(&d_tok_j, (size_t)max_tok * 4));
@@ -572,8 +576,8 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
         }
         if (timed) {
             (void)hipEventRecord(attn_ev[attn_ev_used + 1], s);
-            double keys = 0;
-            for (int r = 0; r < R; ++r) keys += (double)(h_len[r] + n_dec_host + 1);
+            double keys = shared_len;       // the shared uncond prompt is read from HBM once per launch
+            for (int r = 0; r < R; ++r) keys += (double)(h_len[r] + n_dec_host + 1) - ((shared_len > 0 && (r & 1)) ? shared_len : 0);
             attn_ev_bytes.push_back(keys * cfg.n_heads * 128 * 2 * (double)esz);
             attn_ev_used += 2;
         }
@@ -602,6 +606,25 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     if (L_ + cfg.max_new + 1 > max_pos) FAIL(PG_ERR_CAPACITY, "padded length %d too long for the RoPE table (%d)", L_, max_pos);
     if (!ids_dev && !emb_dev) FAIL(PG_ERR_ARG, "ids or embeds required");
     HIPCHK(hipSetDevice(dev));
+    // Shared negative prompt (the uncond prompt is batch-constant for non-edit
+    // data): when every odd row carries the same ids and padding, its prompt is prefetched and
+    // its K/V stored ONCE (row 1); the other uncond rows alias it.  Verified on the host, never
+    // assumed; only on the fused path (no per-position hidden output requested).
+    shared_len = 0;
+    if (share_uncond && fuse_rope && ids_dev && !hidden_out && pmode == 0 && R_ >= 4 && (R_ % 2) == 0) {
+        bool same = true;
+        for (int r = 3; r < R_ && same; r += 2) same = pad_len[r] == pad_len[1];
+        if (same && pad_len[1] < L_) {
+            std::vector<int32_t> hid((size_t)(R_ / 2) * L_);
+            HIPCHK(hipMemcpy2DAsync(hid.data(), (size_t)L_ * 4, ids_dev + L_, (size_t)2 * L_ * 4, (size_t)L_ * 4, R_ / 2,
+                                    hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const int p1 = pad_len[1];
+            for (int r = 1; r < R_ / 2 && same; ++r)
+                same = memcmp(hid.data() + (size_t)r * L_ + p1, hid.data() + p1, (size_t)(L_ - p1) * 4) == 0;
+            if (same) shared_len = L_ - p1;
+        }
+    }
     int ntok = 0;
     h_len.assign(R_, 0);
     int32_t* s_len = h_stage; int32_t* s_off = h_stage + cfg.max_rows; int32_t* s_last = h_stage + 2 * cfg.max_rows;
@@ -612,6 +635,7 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
         const int len = L_ - pad;
         if (len > cfg.max_prompt) FAIL(PG_ERR_CAPACITY, "row %d: %d prompt tokens > max_prompt %d", r, len, cfg.max_prompt);
         h_len[r] = len; s_len[r] = len; s_off[r] = pmode == 0 ? pad : 0;
+        if (shared_len > 0 && (r & 1) && r != 1) { s_last[r] = s_last[1]; continue; }   // aliases row 1's prompt
         for (int j = 0; j < len; ++j) { s_row[ntok] = r; s_j[ntok] = j; s_src[ntok] = r * L_ + pad + j; ++ntok; }
         s_last[r] = ntok - 1;
     }
@@ -673,7 +697,7 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     auto sample = [&](hipStream_t st) {
         if (bf) head_logits<bf16>(st, (const bf16*)hfin, R); else head_logits<float>(st, (const float*)hfin, R);
         sa.logits_partial = part; sa.S = S_last; sa.slab = slab_last;
-        launch_cfg_sample(st, sa, B);
+        launch_cfg_sample(st, sa, B, cfg_pv, cfg_pi);
     };
     if (time_attn) {
         const size_t need = (size_t)2 * cfg.n_layers * T;
@@ -696,7 +720,7 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     if (graph) {
         std::vector<int64_t> key = {R, T, (int64_t)bf, (int64_t)__builtin_bit_cast(int32_t, cfgw),
                                     (int64_t)__builtin_bit_cast(int32_t, temp), (int64_t)seed, (int64_t)force_tok,
-                                    (int64_t)force_mask, (int64_t)out_tok, (int64_t)logits_out};
+                                    (int64_t)force_mask, (int64_t)out_tok, (int64_t)logits_out, (int64_t)shared_len, (int64_t)fuse_rope};
         if (!gexec || key != gkey) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
             hipGraph_t g = nullptr;
@@ -1049,6 +1073,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!h || !key) return PG_ERR_ARG;
     if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
     if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
+    if (!strcmp(key, "share_uncond")) { h->share_uncond = value != 0; return PG_OK; }
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     h->err = std::string("unknown option ") + key;

@@ -69,6 +69,8 @@ struct SeqState {              // device arrays describing the rows of the curre
     const int32_t* n_dec;      // [1] decode steps completed so far
     const int32_t* tok_row;    // [Ntok] prefill: row of packed token t
     const int32_t* tok_j;      // [Ntok] prefill: slot of packed token t
+    int shared_len;            // > 0: odd (uncond CFG) rows share one prompt; its K/V (slots [0, shared_len)) live in row shared_row only
+    int shared_row;
 };
 // qkv partial fp32 [S, M, 3*nh*128] -> RoPE(q), RoPE(k); q -> qbuf T [M, nh*128];
 // k,v -> caches [R][nh][slots][128].  mode 0: decode (token m = row m, slot = len+n_dec);
@@ -108,7 +110,8 @@ struct SampleArgs {
     float* x; int H;                                              // residual stream rows [2B, H]
     const int32_t* n_dec;
 };
-void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B);
+// scratch: >= 16*B floats and ints
+void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B, float* scratch_v, int* scratch_i);
 // greedy text: argmax over vocab of (sum_s partial) per row + EOS bookkeeping, writes
 // out[b, step] (int64) and next-token embedding into x.
 struct TextArgs {

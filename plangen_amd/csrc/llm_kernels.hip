@@ -2,46 +2,66 @@
 // RoPE + KV append, decode attention with per-lane-group online softmax, SwiGLU gate,
 // gen_head activation, fused CFG-mix + argmax / Gumbel-max sampling + next-embedding gather.
 // References: SURVEY.md K1-K9, a6.1-a6.4, a7-a9 (third-party transformers Llama formulas).
+#include <type_traits>
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------- RMSNorm
 // One 256-thread block per row.  x += sum_s partial[s]; xn = w * (x * rsqrt(mean(x^2)+eps)).
 // LlamaRMSNorm: stats in fp32, normalised value cast to the input dtype (fp32 residual
 // stream here) before the weight multiply; the product is rounded once to T.
-template <typename T>
+// Register-resident fast path: H <= NV*1024, thread holds NV float4 (no LDS row buffer), all
+// (S+1)*NV loads are independent and issued up front, weights / outputs moved as 8- or 16-byte
+// vectors.
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ partial,
                                                      int S, long slab, const T* __restrict__ w,
                                                      T* __restrict__ xn, int H, float eps) {
     __shared__ float red[4];
-    extern __shared__ float rowbuf[];           // H floats
     const int m = blockIdx.x, tid = threadIdx.x;
     float* xr = x + (long)m * H;
+    f32x4 v[NV];
     float ss = 0.f;
-    for (int i = tid * 4; i < H; i += 1024) {
-        f32x4 v = *(const f32x4*)(xr + i);
-        for (int s = 0; s < S; ++s) {
-            const f32x4 p = *(const f32x4*)(partial + (long)s * slab + (long)m * H + i);
-            v += p;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid * 4 + j * 1024;
+        v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < H) {
+            v[j] = *(const f32x4*)(xr + i);
+            for (int s = 0; s < S; ++s) v[j] += *(const f32x4*)(partial + (long)s * slab + (long)m * H + i);
+            if (S > 0) *(f32x4*)(xr + i) = v[j];
+            ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
         }
-        if (S > 0) *(f32x4*)(xr + i) = v;
-        *(f32x4*)(rowbuf + i) = v;
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
     ss = block_sum<4>(ss, red);
     if (!xn) return;
     const float rstd = rsqrtf(ss / (float)H + eps);
-    for (int i = tid * 4; i < H; i += 1024) {
-        const f32x4 v = *(const f32x4*)(rowbuf + i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            ET<T>::st(xn + (long)m * H + i + j, ET<T>::ld(w + i + j) * (v[j] * rstd));
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid * 4 + j * 1024;
+        if (i < H) {
+            float o[4];
+            if constexpr (sizeof(T) == 2) {
+                const u32x2 wv = *(const u32x2*)(w + i);
+                o[0] = bf16_lo(wv.x) * (v[j].x * rstd); o[1] = bf16_hi(wv.x) * (v[j].y * rstd);
+                o[2] = bf16_lo(wv.y) * (v[j].z * rstd); o[3] = bf16_hi(wv.y) * (v[j].w * rstd);
+                u32x2 ov; ov.x = pack_bf16x2(o[0], o[1]); ov.y = pack_bf16x2(o[2], o[3]);
+                *(u32x2*)(xn + (long)m * H + i) = ov;
+            } else {
+                const f32x4 wv = *(const f32x4*)(w + i);
+                f32x4 ov = {wv.x * (v[j].x * rstd), wv.y * (v[j].y * rstd), wv.z * (v[j].z * rstd), wv.w * (v[j].w * rstd)};
+                *(f32x4*)(xn + (long)m * H + i) = ov;
+            }
+        }
     }
 }
 template <typename T>
 void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
                     int M, int H, float eps) {
     if (M <= 0) return;
-    hipLaunchKernelGGL(rmsnorm_kernel<T>, dim3(M), dim3(256), H * sizeof(float), s, x, partial, S, slab, w, xn, H, eps);
+    if (H <= 1024) hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps);
+    else if (H <= 2048) hipLaunchKernelGGL((rmsnorm_kernel<T, 2>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps);
+    else if (H <= 4096) hipLaunchKernelGGL((rmsnorm_kernel<T, 4>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps);
+    else hipLaunchKernelGGL((rmsnorm_kernel<T, 8>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps);
 }
 template void launch_rmsnorm<float>(hipStream_t, float*, const float*, int, long, const float*, float*, int, int, float);
 template void launch_rmsnorm<bf16>(hipStream_t, float*, const float*, int, long, const bf16*, bf16*, int, int, float);
@@ -309,56 +329,67 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const float* __r
     float q[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) q[e] = s_q[lk * EPV + e];
-    const T* kb = kc + cbase + lk * EPV;
-    const T* vb = vc + cbase + lk * EPV;
     float m_run = -INFINITY, l_run = 0.f, o[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) o[e] = 0.f;
     constexpr int KPW = KPI * UN;
-    for (int base = w * KPW; base < nprev; base += 4 * KPW) {
-        u32x4 kv[UN], vv[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            int key = base + u * KPI + grp;
-            key = key < nprev ? key : nprev - 1;
-            kv[u] = __builtin_nontemporal_load((const u32x4*)(kb + (long)key * 128));
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            int key = base + u * KPI + grp;
-            key = key < nprev ? key : nprev - 1;
-            vv[u] = __builtin_nontemporal_load((const u32x4*)(vb + (long)key * 128));
-        }
-        float sc[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            float kf[EPV]; ET<T>::unpack(kv[u], kf);
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) d = fmaf(q[e], kf[e], d);
-#pragma unroll
-            for (int o_ = LPK / 2; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
-            sc[u] = (base + u * KPI + grp < nprev) ? d : -INFINITY;
-        }
-        float mx = m_run;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) mx = fmaxf(mx, sc[u]);
-        if (mx > -INFINITY) {
-            const float alpha = __expf(m_run - mx);
-            l_run *= alpha;
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) o[e] *= alpha;
+    // keys [k0, k1) of the (row, head) stream at ``kb/vb``; NTL: non-temporal loads (private
+    // K/V is read exactly once per step) vs cached loads (the shared uncond prompt is re-read by
+    // every uncond row of the batch and should stay in L2).
+    auto run = [&](const T* kb, const T* vb, int k0, int k1, auto ntl) {
+        constexpr bool NTL = decltype(ntl)::value;
+        for (int base = k0 + w * KPW; base < k1; base += 4 * KPW) {
+            u32x4 kv[UN], vv[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const float p = __expf(sc[u] - mx);
-                l_run += p;
-                float vf[EPV]; ET<T>::unpack(vv[u], vf);
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) o[e] = fmaf(p, vf[e], o[e]);
+                int key = base + u * KPI + grp;
+                key = key < k1 ? key : k1 - 1;
+                kv[u] = NTL ? __builtin_nontemporal_load((const u32x4*)(kb + (long)key * 128)) : *(const u32x4*)(kb + (long)key * 128);
             }
-            m_run = mx;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                int key = base + u * KPI + grp;
+                key = key < k1 ? key : k1 - 1;
+                vv[u] = NTL ? __builtin_nontemporal_load((const u32x4*)(vb + (long)key * 128)) : *(const u32x4*)(vb + (long)key * 128);
+            }
+            float sc[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                float kf[EPV]; ET<T>::unpack(kv[u], kf);
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) d = fmaf(q[e], kf[e], d);
+#pragma unroll
+                for (int o_ = LPK / 2; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
+                sc[u] = (base + u * KPI + grp < k1) ? d : -INFINITY;
+            }
+            float mx = m_run;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) mx = fmaxf(mx, sc[u]);
+            if (mx > -INFINITY) {
+                const float alpha = __expf(m_run - mx);
+                l_run *= alpha;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o[e] *= alpha;
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const float p = __expf(sc[u] - mx);
+                    l_run += p;
+                    float vf[EPV]; ET<T>::unpack(vv[u], vf);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) o[e] = fmaf(p, vf[e], o[e]);
+                }
+                m_run = mx;
+            }
         }
+    };
+    int kstart = 0;
+    if (st.shared_len > 0 && (row & 1)) {       // uncond row: prompt K/V live once, in shared_row's region
+        const long sbase = ((long)st.shared_row * nh + head) * slots * 128 + lk * EPV;
+        kstart = st.shared_len < nprev ? st.shared_len : nprev;
+        run(kc + sbase, vc + sbase, 0, kstart, std::false_type{});
     }
+    run(kc + cbase + lk * EPV, vc + cbase + lk * EPV, kstart, nprev, std::true_type{});
     const int stt = w * KPI + grp;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) s_o[stt][lk * EPV + e] = o[e];
@@ -459,14 +490,19 @@ void launch_bias_f32(hipStream_t s, const float* partial, int S, long slab, cons
 __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
-__global__ __launch_bounds__(256) void cfg_sample_kernel(SampleArgs a) {
-    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int s_tok;
-    const int b = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
-    const int B = gridDim.x;
+// Stage 1: grid (CFG_CHUNKS, B): each block scans V/CFG_CHUNKS logits of image b and leaves its
+// local (value, index) winner; stage 2 (one block per image) combines the winners, applies the
+// forcing rules and gathers the next embedding.
+#define CFG_CHUNKS 16
+__global__ __launch_bounds__(256) void cfg_scan_kernel(SampleArgs a, float* __restrict__ pv, int* __restrict__ pi) {
+    __shared__ float sv[4]; __shared__ int si[4];
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
+    const int B = gridDim.y;
+    const int per = (a.V + CFG_CHUNKS - 1) / CFG_CHUNKS, v0 = ch * per, v1 = min(a.V, v0 + per);
     const long rc = (long)(2 * b) * a.V, ru = (long)(2 * b + 1) * a.V;
     float best = -INFINITY; int bi = 0x7fffffff;
     const float invT = a.temperature > 0.f ? 1.f / a.temperature : 1.f;
-    for (int v = tid; v < a.V; v += 256) {
+    for (int v = v0 + tid; v < v1; v += 256) {
         float c = a.bias ? a.bias[v] : 0.f, u = c;
         for (int s = 0; s < a.S; ++s) {
             c += a.logits_partial[(long)s * a.slab + rc + v];
@@ -478,7 +514,7 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(SampleArgs a) {
             const float uu = rng_uniform(a.seed, (uint64_t)b * 1000003ull + step, v);
             mixed = mixed * invT - __logf(-__logf(uu));
         }
-        if (mixed > best) { best = mixed; bi = v; }           // strided ascending: keeps first max
+        if (mixed > best) { best = mixed; bi = v; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -490,6 +526,16 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(SampleArgs a) {
     if (tid == 0) {
         float v = sv[0]; int i = si[0];
         for (int k = 1; k < 4; ++k) argmax_combine(v, i, sv[k], si[k]);
+        pv[b * CFG_CHUNKS + ch] = v; pi[b * CFG_CHUNKS + ch] = i;
+    }
+}
+__global__ __launch_bounds__(256) void cfg_pick_kernel(SampleArgs a, const float* __restrict__ pv, const int* __restrict__ pi) {
+    __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
+    if (tid == 0) {
+        float v = pv[b * CFG_CHUNKS]; int i = pi[b * CFG_CHUNKS];
+        for (int k = 1; k < CFG_CHUNKS; ++k) argmax_combine(v, i, pv[b * CFG_CHUNKS + k], pi[b * CFG_CHUNKS + k]);
+        i = i < 0 ? 0 : (i >= a.V ? a.V - 1 : i);
         int emit = i, feed = i;
         if (step < a.T && a.force_tok) {
             const int f = a.force_tok[(long)b * a.T + step];
@@ -509,8 +555,9 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(SampleArgs a) {
         *(f32x4*)(x0 + a.H + i) = v;
     }
 }
-void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B) {
-    hipLaunchKernelGGL(cfg_sample_kernel, dim3(B), dim3(256), 0, s, a);
+void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B, float* scratch_v, int* scratch_i) {
+    hipLaunchKernelGGL(cfg_scan_kernel, dim3(CFG_CHUNKS, B), dim3(256), 0, s, a, scratch_v, scratch_i);
+    hipLaunchKernelGGL(cfg_pick_kernel, dim3(B), dim3(256), 0, s, a, scratch_v, scratch_i);
 }
 
 // greedy text token (HF generate, do_sample=False): argmax over vocab, finished rows emit
