@@ -97,7 +97,7 @@ struct pg_engine {
     void* vbuf[4] = {nullptr, nullptr, nullptr, nullptr}; long vbuf_elems = 0;
     void *cur = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
     void *aq = nullptr, *ak = nullptr, *avt = nullptr, *ao = nullptr, *ap = nullptr; float* ascore = nullptr;
-    float *gn_stats = nullptr, *gn_ws = nullptr;
+    float *gn_stats = nullptr, *gn_ws = nullptr, *gn_coef = nullptr;
     float* enc_z = nullptr;
     void* stage_dev = nullptr; long stage_bytes = 0;
     // ---- streams / graph / timing
@@ -410,6 +410,7 @@ int pg_engine::create() {
         TRY(dalloc(&ascore, (size_t)cfg.max_images * g2 * g2 * 4));
         TRY(dalloc(&gn_stats, (size_t)cfg.max_images * 64 * 4));
         TRY(dalloc(&gn_ws, (size_t)cfg.max_images * 64 * 4 * 256));
+        TRY(dalloc(&gn_coef, (size_t)cfg.max_images * (cm > 1024 ? cm : 1024) * 2 * 4));
         if (cfg.with_vq_encoder) TRY(dalloc(&enc_z, (size_t)cfg.max_images * g2 * 8 * 4));
     }
     HIPCHK(hipStreamCreateWithFlags(&istream, hipStreamNonBlocking));
@@ -824,8 +825,8 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
 // bf16 error term (measured offline: 5.6e-5 of the 1e-4 pixel-MSE budget).
 template <typename T>
 void pg_engine::gn(hipStream_t s, const NormW& n, const float* in, T* out, int B, int HW, int swish) {
-    launch_gn_stats(s, in, 0, gn_stats, gn_ws, B, HW, n.c, 1e-6f);
-    launch_gn_apply<float, T>(s, in, gn_stats, n.g, n.b, out, B, HW, n.c, swish);
+    launch_gn_stats(s, in, 0, gn_stats, gn_ws, B, HW, n.c, 1e-6f, gn_coef, n.g, n.b);
+    launch_gn_apply<float, T>(s, in, gn_coef, out, B, HW, n.c, swish);
 }
 template <typename T>
 void pg_engine::conv3(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual,
@@ -1138,7 +1139,7 @@ int pg_op_conv3x3(pg_handle h, const void* x_dev, const void* w_dev, const float
 int pg_op_groupnorm(pg_handle h, const void* x_dev, const float* gamma_dev, const float* beta_dev, void* out_dev, int B,
                     int HW, int C, int swish, pg_stream s) {
     if (!h || !x_dev || !out_dev) return PG_ERR_ARG;
-    if (B > h->cfg.max_images) { h->err = "pg_op_groupnorm: B > max_images"; return PG_ERR_CAPACITY; }
+    if (B > h->cfg.max_images || C > 1024) { h->err = "pg_op_groupnorm: B > max_images or C > 1024"; return PG_ERR_CAPACITY; }
     (void)hipSetDevice(h->dev);
     NormW n; n.g = (float*)gamma_dev; n.b = (float*)beta_dev; n.c = C;
     if (h->bf) h->gn<bf16>((hipStream_t)s, n, (const float*)x_dev, (bf16*)out_dev, B, HW, swish);

@@ -126,12 +126,14 @@ void launch_advance(hipStream_t s, int32_t* n_dec);
 // NHWC activations of type T.
 template <typename T>
 void launch_vq_gather(hipStream_t s, const T* table, const int32_t* codes, T* out, int n, int C, int vocab);
-// GroupNorm(32, eps) statistics: stats fp32 [B,32,2] = (mean, rstd); ws fp32 scratch >= B*32*2*nsplit
-void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, float* ws, int B, int HW, int C, float eps);
-// y = gn(x)*gamma+beta, optional swish
+// GroupNorm(32, eps): statistics -> stats fp32 [B,32,2] = (mean, rstd) and, when coef != null,
+// per-(image, channel) affine coefficients coef fp32 [B,C,2] = (rstd*gamma, beta - mean*rstd*gamma).
+// ws: fp32 scratch >= B*32*2*nsplit
+void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, float* ws, int B, int HW, int C, float eps,
+                     float* coef, const float* gamma, const float* beta);
+// y = x*a + sh, optional swish
 template <typename TI, typename TO>
-void launch_gn_apply(hipStream_t s, const TI* x, const float* stats, const float* gamma, const float* beta,
-                     TO* y, int B, int HW, int C, int swish);
+void launch_gn_apply(hipStream_t s, const TI* x, const float* coef, TO* y, int B, int HW, int C, int swish);
 // softmax over rows of fp32 [rows, n] * scale -> T
 template <typename T>
 void launch_softmax_rows(hipStream_t s, const float* x, T* y, int rows, int n, float scale);

@@ -3,6 +3,7 @@
 // row softmax for the single-head AttnBlock, the Cout=3 output conv, the Cin=3 input conv and
 // the nearest-code argmin of the encoder.  Activations are NHWC (channels contiguous) so a
 // pixel's channels are one coalesced run.  Reference: three_party/Janus/janus/models/vq_model.py.
+#include <type_traits>
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------- gather
@@ -65,70 +66,95 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         o[0] = gs; o[1] = gq;
     }
 }
-__global__ void gn_finalize_kernel(const float* __restrict__ ws, float* __restrict__ stats, int nsplit, double cnt, float eps) {
-    const int b = blockIdx.x, g = threadIdx.x;
-    double s = 0.0, q = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) {
-        const float* o = ws + (((long)b * nsplit + sp) * 32 + g) * 2;
-        s += (double)o[0]; q += (double)o[1];
+// Combine the split partials (double) and emit per-(image, channel) affine coefficients:
+// y = x * coef[b][c][0] + coef[b][c][1]  with  a = rstd*gamma, sh = beta - mean*rstd*gamma.
+__global__ void gn_finalize_kernel(const float* __restrict__ ws, float* __restrict__ stats, float* __restrict__ coef,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, int nsplit,
+                                   double cnt, float eps, int C) {
+    __shared__ float s_mean[32], s_rstd[32];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < 32) {
+        double s = 0.0, q = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* o = ws + (((long)b * nsplit + sp) * 32 + t) * 2;
+            s += (double)o[0]; q += (double)o[1];
+        }
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+        stats[((long)b * 32 + t) * 2 + 0] = mf; stats[((long)b * 32 + t) * 2 + 1] = rf;
+        s_mean[t] = mf; s_rstd[t] = rf;
     }
-    const double mean = s / cnt;
-    double var = q / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[((long)b * 32 + g) * 2 + 0] = (float)mean;
-    stats[((long)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    __syncthreads();
+    if (coef) {
+        const int cpg = C / 32;
+        for (int c = t; c < C; c += blockDim.x) {
+            const int g = c / cpg;
+            const float a = s_rstd[g] * gamma[c];
+            coef[((long)b * C + c) * 2 + 0] = a;
+            coef[((long)b * C + c) * 2 + 1] = beta[c] - s_mean[g] * a;
+        }
+    }
 }
 static int gn_nsplit(int HW) { int n = (HW + 1023) / 1024; return n < 1 ? 1 : (n > 256 ? 256 : n); }
-void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, float* ws, int B, int HW, int C, float eps) {
+void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, float* ws, int B, int HW, int C, float eps,
+                     float* coef, const float* gamma, const float* beta) {
     const int nsplit = gn_nsplit(HW);
     const int EPV = is_bf16 ? 8 : 4;
     const int VPP = C / EPV, PL = 256 / VPP > 0 ? 256 / VPP : 1;
     const size_t lds = (size_t)2 * PL * C * sizeof(float);
     if (is_bf16) hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(nsplit, B), dim3(256), lds, s, (const bf16*)x, ws, HW, C, nsplit);
     else hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nsplit, B), dim3(256), lds, s, (const float*)x, ws, HW, C, nsplit);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(32), 0, s, ws, stats, nsplit, (double)HW * (C / 32), eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, ws, stats, coef, gamma, beta, nsplit, (double)HW * (C / 32), eps, C);
 }
 
-// Input TI (fp32 skip stream or T), output TO; EPV elements of the OUTPUT type per thread.
-template <typename TI, typename TO>
-__global__ void gn_apply_kernel(const TI* __restrict__ x, const float* __restrict__ stats,
-                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                TO* __restrict__ y, long HWC, int C, int swish, long total_vec) {
+// y = swish?(x * a[b][c] + sh[b][c]); grid (chunks, B); input TI (fp32 skip stream or T), output TO.
+template <typename TI, typename TO, bool PRECISE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x, const float* __restrict__ coef,
+                                                      TO* __restrict__ y, int C, int swish, long vec_per_img) {
     constexpr int EPV = ET<TO>::EPV;
-    const int cpg = C / 32;
-    for (long vi = (long)blockIdx.x * blockDim.x + threadIdx.x; vi < total_vec; vi += (long)gridDim.x * blockDim.x) {
+    const int b = blockIdx.y;
+    const int vpc = C / EPV;                              // vectors per pixel
+    const TI* xb = x + (long)b * vec_per_img * EPV;
+    TO* yb = y + (long)b * vec_per_img * EPV;
+    const float* cf = coef + (long)b * C * 2;
+    for (long vi = (long)blockIdx.x * 256 + threadIdx.x; vi < vec_per_img; vi += (long)gridDim.x * 256) {
+        const int c0 = (int)(vi % vpc) * EPV;
         const long e0 = vi * EPV;
-        const int b = (int)(e0 / HWC);
-        const int c0 = (int)(e0 % C);
         float f[EPV];
         if constexpr (sizeof(TI) == sizeof(TO)) {
-            const u32x4 v = *(const u32x4*)(x + e0);
+            const u32x4 v = *(const u32x4*)(xb + e0);
             ET<TI>::unpack(v, f);
-        } else {                                   // fp32 in, bf16 out: 2 x 16-byte loads
-            const u32x4 v0 = *(const u32x4*)(x + e0), v1 = *(const u32x4*)(x + e0 + 4);
+        } else {
+            const u32x4 v0 = *(const u32x4*)(xb + e0), v1 = *(const u32x4*)(xb + e0 + 4);
             ET<float>::unpack(v0, f); ET<float>::unpack(v1, f + 4);
         }
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            const int c = c0 + e, g = c / cpg;
-            const float mean = stats[((long)b * 32 + g) * 2], rstd = stats[((long)b * 32 + g) * 2 + 1];
-            float t = (f[e] - mean) * rstd * gamma[c] + beta[c];
-            if (swish) t = t / (1.f + expf(-t));
-            f[e] = t;
+        for (int e = 0; e < EPV; e += 2) {
+            const f32x4 ab = *(const f32x4*)(cf + (c0 + e) * 2);          // a0 sh0 a1 sh1
+            float t0 = fmaf(f[e], ab.x, ab.y), t1 = fmaf(f[e + 1], ab.z, ab.w);
+            if (swish) {
+                t0 = PRECISE ? t0 / (1.f + expf(-t0)) : t0 * __frcp_rn(1.f + __expf(-t0));
+                t1 = PRECISE ? t1 / (1.f + expf(-t1)) : t1 * __frcp_rn(1.f + __expf(-t1));
+            }
+            f[e] = t0; f[e + 1] = t1;
         }
-        *(u32x4*)(y + e0) = ET<TO>::pack(f);
+        *(u32x4*)(yb + e0) = ET<TO>::pack(f);
     }
 }
 template <typename TI, typename TO>
-void launch_gn_apply(hipStream_t s, const TI* x, const float* stats, const float* gamma, const float* beta,
-                     TO* y, int B, int HW, int C, int swish) {
-    const long total_vec = (long)B * HW * C / ET<TO>::EPV;
-    const int blocks = (int)((total_vec + 255) / 256 < 8192 ? (total_vec + 255) / 256 : 8192);
-    hipLaunchKernelGGL((gn_apply_kernel<TI, TO>), dim3(blocks), dim3(256), 0, s, x, stats, gamma, beta, y, (long)HW * C, C, swish, total_vec);
+void launch_gn_apply(hipStream_t s, const TI* x, const float* coef, TO* y, int B, int HW, int C, int swish) {
+    const long vec_per_img = (long)HW * C / ET<TO>::EPV;
+    int blocks = (int)((vec_per_img + 255) / 256);
+    const int cap = 4096 / (B > 0 ? B : 1) + 1;
+    if (blocks > cap) blocks = cap;
+    constexpr bool PRECISE = std::is_same<TO, float>::value;
+    hipLaunchKernelGGL((gn_apply_kernel<TI, TO, PRECISE>), dim3(blocks, B), dim3(256), 0, s, x, coef, y, C, swish, vec_per_img);
 }
-template void launch_gn_apply<float, float>(hipStream_t, const float*, const float*, const float*, const float*, float*, int, int, int, int);
-template void launch_gn_apply<float, bf16>(hipStream_t, const float*, const float*, const float*, const float*, bf16*, int, int, int, int);
-template void launch_gn_apply<bf16, bf16>(hipStream_t, const bf16*, const float*, const float*, const float*, bf16*, int, int, int, int);
+template void launch_gn_apply<float, float>(hipStream_t, const float*, const float*, float*, int, int, int, int);
+template void launch_gn_apply<float, bf16>(hipStream_t, const float*, const float*, bf16*, int, int, int, int);
+template void launch_gn_apply<bf16, bf16>(hipStream_t, const bf16*, const float*, bf16*, int, int, int, int);
 
 // ------------------------------------------------------------------------------- row softmax
 template <typename T>
@@ -153,49 +179,70 @@ template void launch_softmax_rows<float>(hipStream_t, const float*, float*, int,
 template void launch_softmax_rows<bf16>(hipStream_t, const float*, bf16*, int, int, float);
 
 // ------------------------------------------------------------------------------- conv_out (Cout tiny)
-// Thread per output pixel, all Cout (<= 4) channels; weights fp32 in LDS; NHWC in, NCHW out.
+// Cout <= 4 (conv_out 128 -> 3).  A block owns a strip of 64 output pixels of one image row:
+// the 3 x 66-pixel input halo strip is staged in LDS with coalesced 16-byte loads (each input
+// pixel is fetched 3x instead of 9x, and never as 64 different cache lines per instruction),
+// pixel stride padded by 16 B (conflict-free ds_read_b128); 4 threads per pixel split the
+// channels, weights sit in LDS as fp32; NHWC in, NCHW out.
 template <typename T>
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                            const float* __restrict__ bias, void* __restrict__ out,
                                                            int out_bf16, int H, int W, int Cin, int Cout) {
     constexpr int EPV = ET<T>::EPV;
-    extern __shared__ float wl[];                        // [Cout][9][Cin]
-    const int nw = Cout * 9 * Cin;
-    for (int i = threadIdx.x; i < nw; i += 256) wl[i] = ET<T>::ld(w + i);
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int PSTR = Cin * (int)sizeof(T) + 16;                  // padded pixel stride (bytes)
+    float* wl = (float*)(sm + 3 * 66 * PSTR);                    // [Cout][9][Cin] fp32
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 64;
+    for (int i = tid; i < Cout * 9 * Cin; i += 256) wl[i] = ET<T>::ld(w + i);
+    const int vpp = Cin / EPV;                                   // 16-byte vectors per pixel
+    for (int v = tid; v < 3 * 66 * vpp; v += 256) {
+        const int cv = v % vpp, p = (v / vpp) % 66, r = v / (vpp * 66);
+        const int sy = y + r - 1, sx = x0 + p - 1;
+        u32x4 val = (u32x4){0u, 0u, 0u, 0u};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) val = *(const u32x4*)(x + (((long)b * H + sy) * W + sx) * Cin + cv * EPV);
+        *(u32x4*)(sm + (r * 66 + p) * PSTR + cv * 16) = val;
+    }
     __syncthreads();
-    const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
-    const int y = p / W, xx = p % W;
+    const int pix = tid >> 2, q = tid & 3;                       // 64 pixels x 4 channel quarters
+    const int cq = Cin / 4;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int tap = 0; tap < 9; ++tap) {
-        const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
-        if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
-        const T* xp = x + (((long)b * H + sy) * W + sx) * Cin;
-        for (int c = 0; c < Cin; c += EPV) {
-            const u32x4 v = *(const u32x4*)(xp + c);
+        const char* xp = sm + ((tap / 3) * 66 + pix + tap % 3) * PSTR + q * cq * (int)sizeof(T);
+        for (int c = 0; c < cq; c += EPV) {
+            const u32x4 v = *(const u32x4*)(xp + c * sizeof(T));
             float f[EPV]; ET<T>::unpack(v, f);
 #pragma unroll
             for (int co = 0; co < 4; ++co) {
                 if (co < Cout) {
-                    const float* wp = wl + (co * 9 + tap) * Cin + c;
+                    const float* wp = wl + (co * 9 + tap) * Cin + q * cq + c;
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) acc[co] = fmaf(f[e], wp[e], acc[co]);
                 }
             }
         }
     }
-    for (int co = 0; co < Cout; ++co) {
-        const float v = acc[co] + bias[co];
-        const long o = (((long)b * Cout + co) * H + y) * W + xx;
-        if (out_bf16) ET<bf16>::st((bf16*)out + o, v); else ((float*)out)[o] = v;
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        acc[co] += __shfl_xor(acc[co], 1, 64);
+        acc[co] += __shfl_xor(acc[co], 2, 64);
+    }
+    const int xx = x0 + pix;
+    if (q == 0 && xx < W) {
+        for (int co = 0; co < Cout; ++co) {
+            const float v = acc[co] + bias[co];
+            const long o = (((long)b * Cout + co) * H + y) * W + xx;
+            if (out_bf16) ET<bf16>::st((bf16*)out + o, v); else ((float*)out)[o] = v;
+        }
     }
 }
 template <typename T>
 void launch_conv3x3_small(hipStream_t s, const T* x, const T* w, const float* bias, void* out, int out_bf16,
                           int B, int H, int W, int Cin, int Cout) {
-    hipLaunchKernelGGL(conv3x3_small_kernel<T>, dim3((H * W + 255) / 256, B), dim3(256), (size_t)Cout * 9 * Cin * sizeof(float), s,
-                       x, w, bias, out, out_bf16, H, W, Cin, Cout);
+    const size_t lds = (size_t)3 * 66 * (Cin * sizeof(T) + 16) + (size_t)Cout * 9 * Cin * sizeof(float);
+    auto kfn = conv3x3_small_kernel<T>;
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3((W + 63) / 64, H, B), dim3(256), lds, s, x, w, bias, out, out_bf16, H, W, Cin, Cout);
 }
 template void launch_conv3x3_small<float>(hipStream_t, const float*, const float*, const float*, void*, int, int, int, int, int, int);
 template void launch_conv3x3_small<bf16>(hipStream_t, const bf16*, const bf16*, const float*, void*, int, int, int, int, int, int);
