@@ -183,8 +183,16 @@ def main():
         eng.set_option("time_attn", 0)
         if ta["attn_launches"]:
             ach = ta["attn_bytes_sum"] / (ta["attn_ms_sum"] * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "attn_kernel (decode attention)", "achieved": ach, "peak": 8000.0,
-                               "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+            # PMC traffic cannot be collected from inside this process: it comes from separate
+            # rocprofv3 --pmc passes of this same command (profiles/r01_b_pmc_attn_traffic.md);
+            # the measured traffic / algorithmic ratio of the kernel is applied to this run's bytes.
+            traffic = None
+            pj = os.path.join(ROOT, "profiles", "pmc_attn.json")
+            if os.path.exists(pj):
+                ratio = json.load(open(pj))["traffic_per_algorithmic_byte"]
+                traffic = ratio * ta["attn_bytes_sum"] / ta["attn_launches"]
+            out["roofline"] = {"bound": "hbm", "kernel": "attn_decode_fused_kernel (RoPE + KV append + decode attention)",
+                               "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
                                "launches": ta["attn_launches"], "avg_launch_us": ta["attn_ms_sum"] / ta["attn_launches"] * 1e3,
                                "algorithmic_bytes_per_launch": ta["attn_bytes_sum"] / ta["attn_launches"],
                                "decode_loop_share": ta["attn_ms_sum"] / max(ta["decode_ms"], 1e-9)}

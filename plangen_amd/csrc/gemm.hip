@@ -302,14 +302,13 @@ template void launch_gemm<bf16>(hipStream_t, const GemmA&, const bf16*, long, lo
 #define SK_ROWB 288           // LDS row stride (256 B of k + 32 B pad: conflict-free ds_read_b128 for the (lr, g) fragment order)
 
 
-// Block epilogue of the skinny kernels: the 4 waves' accumulators (MFMA C layout: lane holds
+// Block epilogue of the skinny kernels: the NW waves' accumulators (MFMA C layout: lane holds
 // 4 rows x 1 column) are transposed through LDS so every lane stores 16 contiguous bytes
-// (16 lanes = one 256-byte output row segment) instead of 32 scattered dword stores.
-// smem must hold MT*16 rows x (64+4) floats and be free (call after the loop's last barrier).
-template <int MT>
+// instead of 32 scattered dword stores.  smem must hold MT*16 rows x (NW*16+4) floats.
+template <int MT, int NW>
 __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)[MT], float* __restrict__ o, int M, int N,
                                                   int mbase, int nbase, int w, int g, int lr, int tid) {
-    constexpr int LD = 68;
+    constexpr int LD = NW * 16 + 4, NTH = NW * 64, V4 = NW * 4;        // float4 per tile row
     float* t = (float*)smem;
     __syncthreads();                                   // every wave is done reading the x tiles
 #pragma unroll
@@ -317,21 +316,20 @@ __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[(mt * 16 + g * 4 + r) * LD + w * 16 + lr] = acc[mt][r];
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int v = tid + j * 256, row = v >> 4, c4 = (v & 15) * 4;
+    for (int v = tid; v < MT * 16 * V4; v += NTH) {
+        const int row = v / V4, c4 = (v % V4) * 4;
         const int m = mbase + row, n = nbase + c4;
         if (m < M && n < N) *(f32x4*)(o + (long)m * N + n) = *(const f32x4*)(t + row * LD + c4);
     }
 }
 
-// SwiGLU epilogue (S == 1 only): the block's 64 columns are 2 x [16 gate | 16 up] (weights
-// interleaved in blocks of 16 at load time), so h = silu(g) * u for 32 output columns comes
-// straight out of the transposed LDS tile; bf16 h [M, I] is written, no fp32 slab, no extra kernel.
-template <int MT>
+// SwiGLU epilogue (S == 1 only): every 16-column n-tile is [8 gate | 8 up] (weights interleaved
+// in blocks of 8 at load time), so h = silu(g) * u for 8 output columns per tile comes straight
+// out of the transposed LDS tile; bf16 h [M, I] is written, no fp32 slab, no extra kernel.
+template <int MT, int NW>
 __device__ __forceinline__ void skinny_store_swiglu(char* smem, const f32x4 (&acc)[MT], bf16* __restrict__ h, int M, int I,
                                                     int mbase, int nblk, int w, int g, int lr, int tid) {
-    constexpr int LD = 68;
+    constexpr int LD = NW * 16 + 4, NTH = NW * 64, OC = NW * 8;        // outputs per tile row
     float* t = (float*)smem;
     __syncthreads();
 #pragma unroll
@@ -339,15 +337,13 @@ __device__ __forceinline__ void skinny_store_swiglu(char* smem, const f32x4 (&ac
 #pragma unroll
         for (int r = 0; r < 4; ++r) t[(mt * 16 + g * 4 + r) * LD + w * 16 + lr] = acc[mt][r];
     __syncthreads();
-    // MT*16 rows x 32 outputs = MT*512 values; thread -> 2 adjacent outputs per pass
-#pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int v = tid + j * 256, row = v >> 4, c2 = (v & 15) * 2;        // c2 in [0,32)
-        const int m = mbase + row, col = nblk * 32 + c2;
+    for (int v = tid; v < MT * 16 * (OC / 2); v += NTH) {
+        const int row = v / (OC / 2), c2 = (v % (OC / 2)) * 2;          // c2 in [0, OC), even
+        const int m = mbase + row, col = nblk * OC + c2;
         if (m < M && col < I) {
-            const int tc = (c2 >> 4) * 32 + (c2 & 15);                        // gate column in the tile
+            const int tc = (c2 >> 3) * 16 + (c2 & 7);                   // gate column in the tile
             const float g0 = t[row * LD + tc], g1 = t[row * LD + tc + 1];
-            const float u0 = t[row * LD + tc + 16], u1 = t[row * LD + tc + 17];
+            const float u0 = t[row * LD + tc + 8], u1 = t[row * LD + tc + 9];
             const float h0 = (g0 / (1.f + expf(-g0))) * u0, h1 = (g1 / (1.f + expf(-g1))) * u1;
             *(uint32_t*)(h + (long)m * I + col) = pack_bf16x2(h0, h1);
         }
@@ -452,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16* __restr
         }
         __syncthreads();
     }
-    skinny_store_tile<MT>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid);
+    skinny_store_tile<MT, 4>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid);
 }
 
 // Split-K count: smallest divisor S of the chunk count that gives enough blocks to keep the
@@ -500,33 +496,34 @@ void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* o
 // rows in flight (the HBM requests of chunk c+D are issued while chunk c computes), the chunk
 // loop is fully unrolled (NCK = chunks per block, compile time) so the ring is statically
 // indexed.  XDB: x tile double-buffered (2 blocks/CU at MT=8) or single-buffered (4 blocks/CU).
-template <int MT, int NCK, int D, bool XDB, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
-                                                          float* __restrict__ out, int M, int N, int K) {
+template <int MT, int NCK, int D, bool XDB, int EPI, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+                                                               float* __restrict__ out, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int XB = MT * 16 * SK_ROWB;
+    constexpr int XB = MT * 16 * SK_ROWB, NTH = 64 * NW, BN = 16 * NW;
+    constexpr int XV = (MT * 256 + NTH - 1) / NTH;                     // x vectors per thread per chunk
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
     const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
-    const int n = blockIdx.x * 64 + w * 16 + lr;
+    const int n = blockIdx.x * BN + w * 16 + lr;
     const int kbeg = split * NCK * SK_BK;
     const bf16* wp = W + (long)(n < N ? n : N - 1) * K + kbeg + g * 8;
     const bf16* xp = x + kbeg;
 
-    u32x4 xs[MT];
+    u32x4 xs[XV];
     auto xload = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int v = tid + j * 256, row = v >> 4, cv = v & 15;
+        for (int j = 0; j < XV; ++j) {
+            const int v = tid + j * NTH, row = v >> 4, cv = v & 15;
             const int m = mbase + row;
-            if (m < M) xs[j] = *(const u32x4*)(xp + (long)m * K + c * SK_BK + cv * 8);
+            if (row < MT * 16 && m < M) xs[j] = *(const u32x4*)(xp + (long)m * K + c * SK_BK + cv * 8);
             else xs[j] = (u32x4){0u, 0u, 0u, 0u};
         }
     };
     auto xstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int v = tid + j * 256, row = v >> 4, cv = v & 15;
-            *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
+        for (int j = 0; j < XV; ++j) {
+            const int v = tid + j * NTH, row = v >> 4, cv = v & 15;
+            if (row < MT * 16) *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
         }
     };
     bf16x8 wr[D][4];
@@ -555,16 +552,17 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny3_kernel(const bf16* __rest
             __syncthreads();
         }
     }
-    if constexpr (EPI == 1) skinny_store_swiglu<MT>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid);
-    else skinny_store_tile<MT>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid);
+    if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid);
+    else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * BN, w, g, lr, tid);
 }
-template <int MT, int NCK, int D, bool XDB, int EPI = 0>
+template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4>
 static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
-    constexpr int LDS = (XDB ? 2 : 1) * MT * 16 * SK_ROWB;
-    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI>;
+    constexpr int XL = (XDB ? 2 : 1) * MT * 16 * SK_ROWB, TL = MT * 16 * (NW * 16 + 4) * 4;
+    constexpr int LDS = XL > TL ? XL : TL;
+    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-    dim3 grid((N + 63) / 64, S, (M + MT * 16 - 1) / (MT * 16)), block(256);
+    dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K);
 }
 template <int D, bool XDB>
@@ -585,16 +583,16 @@ static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out,
 
 
 // ---- production dispatch: v3 (W register ring depth 2, double-buffered x tile) ----
-template <int MT, int EPI>
+template <int MT, int EPI, int NW = 4>
 static bool sk3_prod_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck) {
     switch (nck) {
-        case 1: launch_sk3<MT, 1, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
-        case 2: launch_sk3<MT, 2, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
-        case 4: launch_sk3<MT, 4, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
-        case 8: launch_sk3<MT, 8, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
-        case 11: launch_sk3<MT, 11, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
-        case 16: launch_sk3<MT, 16, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
-        case 22: launch_sk3<MT, 22, 2, true, EPI>(s, x, W, out, M, N, K, S); return true;
+        case 1: launch_sk3<MT, 1, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
+        case 2: launch_sk3<MT, 2, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
+        case 4: launch_sk3<MT, 4, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
+        case 8: launch_sk3<MT, 8, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
+        case 11: launch_sk3<MT, 11, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
+        case 16: launch_sk3<MT, 16, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
+        case 22: launch_sk3<MT, 22, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
         default: return false;
     }
 }
@@ -624,6 +622,15 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 23: return sk3_dispatch<2, false>(s, x, W, out, M, N, K, S) ? 128 : 0;        // x single-buffered
         case 24: return sk3_prod_nck<4, 0>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // 64-row M blocks (grid.z = M/64)
         case 25: return sk3_prod_nck<2, 0>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // 32-row M blocks
+        case 40: {   // MFMA tile kernel (128x128x64, glds) with split-K expressed through the batch strides
+            if (K % (64 * S)) return 0;
+            GemmA a; a.ptr = x; a.lda = K; a.strideA = K / S;
+            GemmEpi e; e.out = out; e.out_f32 = 1; e.ldc = N; e.strideC = (long)M * N;
+            launch_gemm<bf16>(s, a, W, K, K / S, e, M, N, K / S, S);
+            return 64;
+        }
+        case 26: return sk3_prod_nck<8, 0, 3>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;  // 48-column blocks (3 waves)
+        case 27: return sk3_prod_nck<8, 0, 2>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;  // 32-column blocks (2 waves)
         default: return 0;
     }
 }

@@ -90,7 +90,7 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
                               const float* cos_t, const float* sin_t, SeqState st, int M, int nh, int slots,
                               int max_pos, float scale);
 // h = silu(g) * u from gate-up partial fp32 [S, M, 2I] whose columns are interleaved in
-// blocks of 16 (16 gate, 16 up, ...)
+// blocks of 8 (8 gate, 8 up, ...: every 16-column MFMA n-tile holds matching gate/up columns)
 template <typename T>
 void launch_silu_mul(hipStream_t s, const float* gu, int S, long slab, T* h, int M, int I);
 // out T [M,N] = act(sum_s partial + bias)
@@ -155,7 +155,7 @@ void launch_convert(hipStream_t s, const void* src, int src_bf16, T* dst, long n
 // conv weight [Cout][Cin][kh][kw] -> [Cout][kh*kw][Cin]
 template <typename T>
 void launch_convert_conv(hipStream_t s, const void* src, int src_bf16, T* dst, int Cout, int Cin, int kk);
-// gate/up rows interleaved in blocks of 16: src [I,H] -> dst rows (n/16)*32 + which*16 + n%16
+// gate/up rows interleaved in blocks of 8: src [I,H] -> dst rows (n/8)*16 + which*8 + n%8
 template <typename T>
 void launch_convert_interleave16(hipStream_t s, const void* src, int src_bf16, T* dst, int I, int H, int which);
 void launch_to_f32(hipStream_t s, const void* src, int src_bf16, float* dst, long n);

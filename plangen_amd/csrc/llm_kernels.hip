@@ -440,15 +440,15 @@ template void launch_attn<float>(hipStream_t, const float*, float*, const float*
 template void launch_attn<bf16>(hipStream_t, const bf16*, bf16*, const bf16*, const bf16*, SeqState, int, int, int, int, float);
 
 // ------------------------------------------------------------------------------- SwiGLU gate
-// gu columns are interleaved in blocks of 16: [16 gate | 16 up] per 32 columns.
+// gu columns are interleaved in blocks of 8: [8 gate | 8 up] per 16 columns (= one MFMA n-tile).
 template <typename T>
 __global__ void silu_mul_kernel(const float* __restrict__ gu, int S, long slab, T* __restrict__ h, int I) {
     const int m = blockIdx.y;
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= I) return;
-    const long cg = (long)m * 2 * I + (n >> 4) * 32 + (n & 15);
+    const long cg = (long)m * 2 * I + (n >> 3) * 16 + (n & 7);
     float g = 0.f, u = 0.f;
-    for (int s = 0; s < S; ++s) { g += gu[(long)s * slab + cg]; u += gu[(long)s * slab + cg + 16]; }
+    for (int s = 0; s < S; ++s) { g += gu[(long)s * slab + cg]; u += gu[(long)s * slab + cg + 8]; }
     ET<T>::st(h + (long)m * I + n, (g / (1.f + expf(-g))) * u);
 }
 template <typename T>
@@ -645,7 +645,7 @@ __global__ void convert_il16_kernel(const void* __restrict__ src, int src_bf16, 
     const long n = (long)I * H;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const long r = i / H; const int c = (int)(i % H);
-        const long dr = (r >> 4) * 32 + which * 16 + (r & 15);
+        const long dr = (r >> 3) * 16 + which * 8 + (r & 7);
         const float v = src_bf16 ? ET<bf16>::ld((const bf16*)src + i) : ((const float*)src)[i];
         ET<T>::st(dst + dr * H + c, v);
     }
