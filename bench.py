@@ -94,7 +94,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="tiny config (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-steps", type=int, default=64)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=value (pg_set_option)")
     args = ap.parse_args()
 
@@ -199,7 +200,9 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
-        out["cpu_baseline"] = cpu_baseline(L, args.cpu_steps, os.cpu_count() or 1)
+        # 16 threads: measured fastest for these small torch-CPU GEMMs on the 256-core bench host
+        # (ms/step: 16 thr 89, 32 thr 144, 64 thr 298, 256 thr 42 466)
+        out["cpu_baseline"] = cpu_baseline(L, args.cpu_steps, min(args.cpu_threads, os.cpu_count() or 1))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
