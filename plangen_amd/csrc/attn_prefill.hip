@@ -1,0 +1,154 @@
+// Prefill (causal, variable-length, packed) flash attention on MFMA for head_dim 128, bf16.
+//
+// One 256-thread block = 64 consecutive queries of one (row, head); wave w owns 16 of them.
+// Per 64-key tile: K [64][128] and V^T [128][64] are staged in LDS (coalesced 16-byte global
+// loads; V is transposed on the way in so the PV MFMA's B operand is key-contiguous).
+// S^T = K.Q^T is computed with K as the A operand ("swapped" QK^T): the C layout then gives
+// lane (lr, g) the scores of QUERY lr for keys {16*kt + 4*g + r}, which is exactly the A-operand
+// layout of the PV MFMA under a consistent key permutation -- P never goes through LDS -- and a
+// query's softmax statistics need only two cross-lane steps (xor 16, 32).  O accumulates in the
+// C layout (row = query 4*g+r), so the per-query rescale factors are fetched with 4 shuffles.
+// K/V come from the KV cache [row][head][slot][128] that rope_kv_kernel just filled.
+#include "kernels.h"
+
+#define FA_KROW 272          // bytes per K row in LDS (256 + 16 pad)
+#define FA_VROW 144          // bytes per V^T row in LDS (64 keys * 2 + 16 pad)
+
+__global__ __launch_bounds__(256) void attn_prefill_flash_kernel(const bf16* __restrict__ qbuf, bf16* __restrict__ obuf,
+                                                                const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+                                                                const int32_t* __restrict__ row_off, const int32_t* __restrict__ len,
+                                                                int nh, int slots, float scale) {
+    __shared__ __attribute__((aligned(16))) char sK[64 * FA_KROW];
+    __shared__ __attribute__((aligned(16))) char sV[128 * FA_VROW];
+    const int qt = blockIdx.x, head = blockIdx.y, row = blockIdx.z;
+    const int off = row_off[row];
+    const int L = len[row];
+    if (off < 0 || qt * 64 >= L) return;                       // row has no packed tokens here / tile beyond the prompt
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
+    const int HD = nh * 128;
+    const int q0 = qt * 64 + w * 16;                            // first query (slot index) of this wave
+    const int myq = q0 + lr;                                    // the query whose softmax state this lane carries
+    // Q fragments (B operand): lane (q = lr, g) holds Q[q][ds*32 + g*8 .. +8], pre-scaled
+    bf16x8 qf[4];
+    {
+        const int qq = myq < L ? myq : L - 1;
+        const bf16* qp = qbuf + (long)(off + qq) * HD + head * 128 + g * 8;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const u32x4 v = *(const u32x4*)(qp + ds * 32);
+            float f[8]; ET<bf16>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= scale;
+            const u32x4 pv = ET<bf16>::pack(f);
+            qf[ds] = *(const bf16x8*)&pv;
+        }
+    }
+    const bf16* kbase = kc + ((long)row * nh + head) * slots * 128;
+    const bf16* vbase = vc + ((long)row * nh + head) * slots * 128;
+    f32x4 oacc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int qmax = min(qt * 64 + 63, L - 1);                  // last query of the block
+    const int ntiles = qmax / 64 + 1;                           // causal: keys 0 .. qmax
+    for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+        const int kb = kt0 * 64;
+        __syncthreads();                                        // previous tile fully consumed
+        // ---- stage K (row-major) and V (transposed) for keys kb .. kb+63
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int v = tid + j * 256, key = v >> 4, cv = v & 15;
+            const int ks = (kb + key < L) ? kb + key : L - 1;
+            const u32x4 kv = *(const u32x4*)(kbase + (long)ks * 128 + cv * 8);
+            *(u32x4*)(sK + key * FA_KROW + cv * 16) = kv;
+            const u32x4 vv = *(const u32x4*)(vbase + (long)ks * 128 + cv * 8);
+            const uint16_t* ve = (const uint16_t*)&vv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(uint16_t*)(sV + (cv * 8 + e) * FA_VROW + key * 2) = ve[e];
+        }
+        __syncthreads();
+        // ---- S^T[key][q] = sum_d K[key][d] Q[q][d] : 4 key sub-tiles x 4 d-steps
+        f32x4 sacc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            sacc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const bf16x8 ka = *(const bf16x8*)(sK + (kt * 16 + lr) * FA_KROW + (ds * 32 + g * 8) * 2);
+                sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ds], sacc[kt], 0, 0, 0);
+            }
+        }
+        // lane (lr, g): query myq, keys kb + kt*16 + g*4 + r
+        float mx = m_run;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb + kt * 16 + g * 4 + r;
+                if (key > myq || key >= L) sacc[kt][r] = -INFINITY;        // causal + length mask
+                mx = fmaxf(mx, sacc[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // key 0 <= every query, so mx is finite from the first tile on
+        const float alpha = __expf(m_run - mx);
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float p[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = __expf(sacc[2 * s][r] - mx);
+                p[4 + r] = __expf(sacc[2 * s + 1][r] - mx);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) psum += p[e];
+            const u32x4 pv = ET<bf16>::pack(p);
+            pf[s] = *(const bf16x8*)&pv;
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = mx;
+        // ---- rescale O rows (row = query g*4+r of this wave) by that query's alpha
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) oacc[dt][r] *= a;
+        }
+        // ---- O[q][d] += P[q][keys] V[keys][d] : k-step s covers key sub-tiles 2s, 2s+1;
+        //      B operand lane (d = dt*16+lr, g): keys {2s*16+g*4..+3, (2s+1)*16+g*4..+3}
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const char* vr = sV + (dt * 16 + lr) * FA_VROW;
+                const u32x2 lo = *(const u32x2*)(vr + ((2 * s) * 16 + g * 4) * 2);
+                const u32x2 hi = *(const u32x2*)(vr + ((2 * s + 1) * 16 + g * 4) * 2);
+                u32x4 vb; vb.x = lo.x; vb.y = lo.y; vb.z = hi.x; vb.w = hi.y;
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[s], *(const bf16x8*)&vb, oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise and store: row q = q0 + g*4 + r, column d = dt*16 + lr
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lq = __shfl(l_run, g * 4 + r, 64);
+        const int q = q0 + g * 4 + r;
+        if (q < L) {
+            const float inv = 1.f / lq;
+            bf16* op = obuf + (long)(off + q) * HD + head * 128 + lr;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) ET<bf16>::st(op + dt * 16, oacc[dt][r] * inv);
+        }
+    }
+}
+
+void launch_attn_prefill_flash(hipStream_t s, const bf16* qbuf, bf16* obuf, const bf16* kc, const bf16* vc,
+                               const int32_t* row_off, const int32_t* len, int R, int max_len, int nh, int slots, float scale) {
+    if (R <= 0 || max_len <= 0) return;
+    hipLaunchKernelGGL(attn_prefill_flash_kernel, dim3((max_len + 63) / 64, nh, R), dim3(256), 0, s, qbuf, obuf, kc, vc, row_off, len,
+                       nh, slots, scale);
+}

@@ -85,7 +85,8 @@ struct pg_engine {
     int n_dec_host = 0;
     std::vector<int> h_len;
     int32_t *d_len = nullptr, *d_pos_off = nullptr, *d_ndec = nullptr, *d_tok_row = nullptr, *d_tok_j = nullptr,
-            *d_tok_src = nullptr, *d_last = nullptr, *d_unf = nullptr, *d_anyunf = nullptr;
+            *d_tok_src = nullptr, *d_last = nullptr, *d_unf = nullptr, *d_anyunf = nullptr, *d_row_off = nullptr;
+    int max_len_host = 0; bool flash_prefill = true;
     int32_t* h_stage = nullptr;                                  // pinned host staging
     float* cfg_pv = nullptr; int* cfg_pi = nullptr;              // sampler stage-1 winners
     void* kv = nullptr;
@@ -352,6 +353,7 @@ int pg_engine::create() {
     TRY(dalloc(&d_len, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_pos_off, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_last, (size_t)cfg.max_rows * 4));
+    TRY(dalloc(&d_row_off, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_unf, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_anyunf, 1024 * 4));
     TRY(dalloc(&d_ndec, 64));
@@ -573,7 +575,16 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
             launch_rope_kv<T>(s, part, S_last, slab_last, (T*)qbuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), mode, M,
                               cfg.n_heads, slots, max_pos);
             if (timed) (void)hipEventRecord(attn_ev[attn_ev_used], s);
-            launch_attn<T>(s, (const T*)qbuf, (T*)obuf, (const T*)kc(li), (const T*)vc(li), seq(), mode, M, cfg.n_heads, slots, scale);
+            bool done = false;
+            if constexpr (std::is_same<T, bf16>::value) {
+                if (mode == 1 && flash_prefill) {
+                    launch_attn_prefill_flash(s, (const bf16*)qbuf, (bf16*)obuf, (const bf16*)kc(li), (const bf16*)vc(li), d_row_off, d_len,
+                                              R, max_len_host, cfg.n_heads, slots, scale);
+                    done = true;
+                }
+            }
+            if (!done)
+                launch_attn<T>(s, (const T*)qbuf, (T*)obuf, (const T*)kc(li), (const T*)vc(li), seq(), mode, M, cfg.n_heads, slots, scale);
         }
         if (timed) {
             (void)hipEventRecord(attn_ev[attn_ev_used + 1], s);
@@ -629,6 +640,7 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     int ntok = 0;
     h_len.assign(R_, 0);
     int32_t* s_len = h_stage; int32_t* s_off = h_stage + cfg.max_rows; int32_t* s_last = h_stage + 2 * cfg.max_rows;
+    int32_t* s_roff = h_stage + 3 * cfg.max_rows; max_len_host = 0;
     int32_t* s_row = h_stage + 4 * cfg.max_rows; int32_t* s_j = s_row + max_tok; int32_t* s_src = s_j + max_tok;
     for (int r = 0; r < R_; ++r) {
         const int pad = pad_len[r];
@@ -636,7 +648,8 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
         const int len = L_ - pad;
         if (len > cfg.max_prompt) FAIL(PG_ERR_CAPACITY, "row %d: %d prompt tokens > max_prompt %d", r, len, cfg.max_prompt);
         h_len[r] = len; s_len[r] = len; s_off[r] = pmode == 0 ? pad : 0;
-        if (shared_len > 0 && (r & 1) && r != 1) { s_last[r] = s_last[1]; continue; }   // aliases row 1's prompt
+        if (shared_len > 0 && (r & 1) && r != 1) { s_last[r] = s_last[1]; s_roff[r] = -1; continue; }   // aliases row 1's prompt
+        s_roff[r] = ntok; if (len > max_len_host) max_len_host = len;
         for (int j = 0; j < len; ++j) { s_row[ntok] = r; s_j[ntok] = j; s_src[ntok] = r * L_ + pad + j; ++ntok; }
         s_last[r] = ntok - 1;
     }
@@ -645,6 +658,7 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     HIPCHK(hipMemcpyAsync(d_len, s_len, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_pos_off, s_off, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_last, s_last, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_row_off, s_roff, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_tok_row, s_row, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_tok_j, s_j, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_tok_src, s_src, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
@@ -1075,6 +1089,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
     if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
     if (!strcmp(key, "share_uncond")) { h->share_uncond = value != 0; return PG_OK; }
+    if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     h->err = std::string("unknown option ") + key;

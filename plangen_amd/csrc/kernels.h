@@ -84,6 +84,9 @@ void launch_rope_kv(hipStream_t s, const float* qkv, int S, long slab, T* qbuf, 
 template <typename T>
 void launch_attn(hipStream_t s, const T* qbuf, T* obuf, const T* kc, const T* vc, SeqState st, int mode,
                  int M, int nh, int slots, float scale);
+// prefill: causal varlen flash attention on MFMA (bf16, head_dim 128); row_off[r] = first packed token of row r or -1
+void launch_attn_prefill_flash(hipStream_t s, const bf16* qbuf, bf16* obuf, const bf16* kc, const bf16* vc,
+                               const int32_t* row_off, const int32_t* len, int R, int max_len, int nh, int slots, float scale);
 // decode step: RoPE + KV append + attention in one kernel (reads the QKV split-K slabs)
 template <typename T>
 void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc,

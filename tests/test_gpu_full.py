@@ -143,3 +143,21 @@ def test_large_batch_decode_path_matches_small_batch_path():
         assert torch.equal(big[0::2], big[0:1].expand(64, -1)) and torch.equal(big[1::2], big[1:2].expand(64, -1))
         assert (big[:2] - small).abs().max() < 0.02 * small.abs().max()
     e.close()
+
+
+def test_flash_prefill_matches_streaming_attention():
+    """MFMA flash prefill attention vs the per-query streaming kernel on ragged left-padded rows."""
+    e = full_engine()
+    ids, pad = _prompts(3, 64, [64, 37, 50], seed=7)
+    outs = []
+    for flash in (1, 0):
+        e.set_option("flash_prefill", flash)
+        e.set_option("share_uncond", 0)
+        outs.append(e.prefill(ids, pad, return_hidden=True).cpu())
+    e.set_option("flash_prefill", 1)
+    e.set_option("share_uncond", 1)
+    real = torch.ones(ids.shape, dtype=torch.bool)
+    for r, p in enumerate(pad):
+        real[r, :p] = False
+    d = (outs[0] - outs[1])[real].abs().max()
+    assert d < 0.03 * outs[1][real].abs().max(), d
