@@ -60,6 +60,10 @@ typedef struct pg_config {
     int32_t max_images;      /* VQ decode batch capacity */
     int32_t with_lm_head;    /* allocate lm_head (text/layout decode, a11) */
     int32_t with_vq_encoder; /* allocate VQ encoder (a14) */
+    /* SigLIP understanding encoder + aligner (a13, task_type='mmu'); siglip_large_patch16_384:
+       width 1024, 24 layers, 16 heads (64 each), MLP 4096, patch 16, image 384 (siglip_vit.py:628-637) */
+    int32_t with_vision, vit_width, vit_layers, vit_heads, vit_mlp, vit_patch, vit_img;
+    int32_t max_vision_images;   /* images per pg_vision_encode call */
 } pg_config;
 
 /* -- lifetime ------------------------------------------------------------------------ */
@@ -149,6 +153,15 @@ int pg_vq_decode(pg_handle h, const int32_t* codes_dev, void* img_out_dev, int o
 /* gen_vision_model.encode(x)[-1][-1] (vq_model.py:494-498; plangen_base.py:532):
  * img_dev [B,3,S,S] -> idx_out_dev int64 [B*g*g]. */
 int pg_vq_encode(pg_handle h, const void* img_dev, int img_dtype, int64_t* idx_out_dev, int B, pg_stream s);
+
+/* -- understanding encoder ------------------------------------------------------------------ */
+/* aligner(vision_model(images)) of MultiModalityCausalLM.prepare_inputs_embeds
+ * (modeling_vlm.py:243-250): CLIPVisionTower.forward (clip_encoder.py:107-122) ->
+ * VisionTransformer.forward_features (siglip_vit.py:562-572; no cls token, learned pos-embed,
+ * LayerNorm eps 1e-6, non-causal MHA, GELU MLP) -> MlpProjector mlp_gelu (projector.py:38-44).
+ * img_dev [B,3,S,S] -> out_dev [B, (S/patch)^2, hidden].  The masked scatter into the text
+ * embeddings (modeling_vlm.py:263-266) is data movement done by the caller. */
+int pg_vision_encode(pg_handle h, const void* img_dev, int img_dtype, void* out_dev, int out_dtype, int B, pg_stream s);
 
 /* -- introspection (tests / bench) -------------------------------------------------------- */
 /* Last-launch timing of the decode loop measured with HIP events on ``s`` inside the

@@ -30,7 +30,8 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 TINY = dict(hidden=256, inter=512, n_layers=2, n_heads=2, head_dim=128, vocab=512,
             img_vocab=256, img_dim=8, grid=8, gen_head_dim=256, vq_ch=64,
-            vq_ch_mult=(1, 2, 2), vq_z=64, eos_id=7, pad_id=3)
+            vq_ch_mult=(1, 2, 2), vq_z=64, eos_id=7, pad_id=3,
+            vit_width=128, vit_layers=2, vit_heads=2, vit_mlp=256, vit_patch=8, vit_img=64)
 
 
 def _load(name, path):

@@ -22,6 +22,8 @@ class pg_config(C.Structure):
         ("compute_dtype", C.c_int32), ("max_rows", C.c_int32), ("max_prompt", C.c_int32),
         ("max_new", C.c_int32), ("max_images", C.c_int32), ("with_lm_head", C.c_int32),
         ("with_vq_encoder", C.c_int32),
+        ("with_vision", C.c_int32), ("vit_width", C.c_int32), ("vit_layers", C.c_int32), ("vit_heads", C.c_int32),
+        ("vit_mlp", C.c_int32), ("vit_patch", C.c_int32), ("vit_img", C.c_int32), ("max_vision_images", C.c_int32),
     ]
 
 
@@ -48,6 +50,7 @@ SYMBOLS = [
     ("pg_generate_text_greedy", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.POINTER(C.c_int), _P]),
     ("pg_vq_decode", C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     ("pg_vq_encode", C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P]),
+    ("pg_vision_encode", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
     ("pg_get_timing", C.c_int, [_P, C.POINTER(pg_timing)]),
     ("pg_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("pg_device_bytes", C.c_int64, [_P]),

@@ -25,6 +25,13 @@ class PlanGenConfig:
     vq_ch_mult: Tuple[int, ...] = (1, 1, 2, 2, 4)
     vq_z: int = 256
     vq_res_blocks: int = 2
+    # SigLIP-L/16-384 understanding encoder (siglip_vit.py:628-637) + aligner
+    vit_width: int = 1024
+    vit_layers: int = 24
+    vit_heads: int = 16
+    vit_mlp: int = 4096
+    vit_patch: int = 16
+    vit_img: int = 384
     eos_id: int = 100001           # conversation.py:306
     pad_id: int = 100002           # <｜▁pad▁｜>; numeric id lives in the HF tokenizer files
     # sampling defaults (cfg/base.py:158-162)
@@ -37,13 +44,18 @@ class PlanGenConfig:
         return self.grid * self.grid
 
     @property
+    def vit_tokens(self) -> int:
+        return (self.vit_img // self.vit_patch) ** 2
+
+    @property
     def img_size(self) -> int:
         return self.grid * (2 ** (len(self.vq_ch_mult) - 1))
 
     def model_dict(self) -> dict:
         """Fields shared with the test oracle's config."""
         keys = ("hidden inter n_layers n_heads head_dim vocab rms_eps rope_theta img_vocab img_dim grid "
-                "gen_head_dim vq_ch vq_ch_mult vq_z vq_res_blocks eos_id pad_id").split()
+                "gen_head_dim vq_ch vq_ch_mult vq_z vq_res_blocks eos_id pad_id "
+                "vit_width vit_layers vit_heads vit_mlp vit_patch vit_img").split()
         d = asdict(self)
         return {k: d[k] for k in keys}
 
@@ -57,4 +69,5 @@ class PlanGenConfig:
         8x8 image tokens, 3-level VQ decoder -> 32x32 images."""
         return PlanGenConfig(hidden=256, inter=512, n_layers=2, n_heads=2, head_dim=128, vocab=512,
                              img_vocab=256, img_dim=8, grid=8, gen_head_dim=256, vq_ch=64,
-                             vq_ch_mult=(1, 2, 2), vq_z=64, eos_id=7, pad_id=3)
+                             vq_ch_mult=(1, 2, 2), vq_z=64, eos_id=7, pad_id=3,
+                             vit_width=128, vit_layers=2, vit_heads=2, vit_mlp=256, vit_patch=8, vit_img=64)

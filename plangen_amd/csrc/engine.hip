@@ -52,6 +52,8 @@ struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; };
 struct ResBlockW { NormW n1, n2; ConvW c1, c2, nin; bool has_nin = false; };
 struct AttnW { NormW n; ConvW q, k, v, p; };
 struct VqLevel { std::vector<ResBlockW> res; std::vector<AttnW> attn; ConvW resample; bool has_resample = false; };
+struct LinW { void* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
+struct VitBlockW { NormW n1, n2; LinW qkv, proj, fc1, fc2; };
 struct VqNet { ConvW conv_in; ResBlockW mid0, mid2; AttnW mid1; std::vector<VqLevel> levels; NormW norm_out; ConvW conv_out; };
 
 struct pg_engine {
@@ -76,6 +78,10 @@ struct pg_engine {
     void* qc_w = nullptr; float* qc_b = nullptr;                 // encoder quant_conv (z -> img_dim)
     float *enc_in_w = nullptr, *enc_in_b = nullptr;              // encoder conv_in (3 -> ch), fp32 [Cout][3][3][3]
     VqNet dec, enc;
+    // SigLIP + aligner (a13)
+    LinW vit_patch, al0, al2; float* vit_pos = nullptr; std::vector<VitBlockW> vit_blocks; NormW vit_norm;
+    float* vx = nullptr; void *vt = nullptr, *vqk = nullptr, *vvt = nullptr, *vo = nullptr, *vh = nullptr, *vp = nullptr, *val = nullptr;
+    float* vscore = nullptr;
     float *cos_t = nullptr, *sin_t = nullptr; int max_pos = 0;
     void* zeros = nullptr;
     bool finalized = false;
@@ -135,6 +141,10 @@ struct pg_engine {
     int alloc_res(const std::string& name, ResBlockW& r, int cin, int cout);
     int alloc_attn(const std::string& name, AttnW& a, int c);
     int build_vq();
+    int alloc_lin(const std::string& name, LinW& l, int out, int in);
+    int build_vision();
+    template <typename T> void lin(hipStream_t s, const LinW& l, const T* in, void* out, int out_f32, const void* residual, int res_f32, int act, long M);
+    template <typename T> int vision_encode(const void* img, int img_dtype, void* out, int out_dtype, int B, hipStream_t s);
     int load_tensor(const char* name, const void* src, int dtype, const int64_t* shape, int ndim);
     int finalize(int* missing, hipStream_t s);
     int prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtype, const int32_t* pad_len, int R_, int L_,
@@ -267,6 +277,52 @@ int pg_engine::build_vq() {
     return PG_OK;
 }
 
+int pg_engine::alloc_lin(const std::string& name, LinW& l, int out, int in) {
+    l.out = out; l.in = in;
+    TRY(dalloc(&l.w, (size_t)out * in * esz));
+    TRY(dalloc(&l.b, (size_t)out * 4));
+    add_slot(name + ".weight", l.w, K_T, (long)out * in);
+    add_slot(name + ".bias", l.b, K_F32, out);
+    return PG_OK;
+}
+// CLIPVisionTower(siglip_large_patch16_384) + aligner: clip_encoder.py:30-122, siglip_vit.py:262-572,
+// modeling_vlm.py:196-202.  State-dict names as in the Janus-Pro checkpoints.
+int pg_engine::build_vision() {
+    const int C = cfg.vit_width, ps = cfg.vit_patch, P = (cfg.vit_img / ps) * (cfg.vit_img / ps), Hh = H();
+    if (cfg.vit_heads < 1 || C != cfg.vit_heads * 64) FAIL(PG_ERR_ARG, "SigLIP head_dim must be 64 (width %d, heads %d)", C, cfg.vit_heads);
+    if (C % 64 || cfg.vit_mlp % 64 || (3 * ps * ps) % 16) FAIL(PG_ERR_ARG, "vit_width / vit_mlp must be multiples of 64");
+    if (bf && (P % 64 || (3 * ps * ps) % 64)) FAIL(PG_ERR_ARG, "bf16 mode needs patch count and 3*patch^2 to be multiples of 64");
+    const std::string VT = "vision_model.vision_tower.";
+    TRY(alloc_lin(VT + "patch_embed.proj", vit_patch, C, 3 * ps * ps));
+    TRY(dalloc(&vit_pos, (size_t)P * C * 4));
+    add_slot(VT + "pos_embed", vit_pos, K_F32, (long)P * C);
+    vit_blocks.resize(cfg.vit_layers);
+    for (int i = 0; i < cfg.vit_layers; ++i) {
+        const std::string b = VT + "blocks." + std::to_string(i) + ".";
+        VitBlockW& w = vit_blocks[i];
+        TRY(alloc_norm(b + "norm1", w.n1, C));
+        TRY(alloc_lin(b + "attn.qkv", w.qkv, 3 * C, C));
+        TRY(alloc_lin(b + "attn.proj", w.proj, C, C));
+        TRY(alloc_norm(b + "norm2", w.n2, C));
+        TRY(alloc_lin(b + "mlp.fc1", w.fc1, cfg.vit_mlp, C));
+        TRY(alloc_lin(b + "mlp.fc2", w.fc2, C, cfg.vit_mlp));
+    }
+    TRY(alloc_norm(VT + "norm", vit_norm, C));
+    TRY(alloc_lin("aligner.layers.0", al0, Hh, C));
+    TRY(alloc_lin("aligner.layers.2", al2, Hh, Hh));
+    const long nb = cfg.max_vision_images, M = nb * P;
+    TRY(dalloc(&vx, (size_t)M * C * 4));
+    TRY(dalloc(&vt, (size_t)M * (C > 3 * ps * ps ? C : 3 * ps * ps) * esz));
+    TRY(dalloc(&vqk, (size_t)M * 2 * C * esz));
+    TRY(dalloc(&vvt, (size_t)M * C * esz));
+    TRY(dalloc(&vo, (size_t)M * C * esz));
+    TRY(dalloc(&vh, (size_t)M * cfg.vit_mlp * esz));
+    TRY(dalloc(&val, (size_t)M * Hh * esz));
+    TRY(dalloc(&vscore, (size_t)nb * cfg.vit_heads * P * P * 4));
+    TRY(dalloc(&vp, (size_t)nb * cfg.vit_heads * P * P * esz));
+    return PG_OK;
+}
+
 int pg_engine::create() {
     bf = cfg.compute_dtype == PG_BF16;
     esz = bf ? 2 : 4;
@@ -340,6 +396,7 @@ int pg_engine::create() {
     add_slot("gen_vision_model.post_quant_conv.weight", pq_w, K_F32, (long)cfg.vq_z * Dm);
     add_slot("gen_vision_model.post_quant_conv.bias", pq_b, K_F32, cfg.vq_z);
     TRY(build_vq());
+    if (cfg.with_vision) TRY(build_vision());
 
     // ---- state + workspaces
     slots = cfg.max_prompt + cfg.max_new;
@@ -976,6 +1033,60 @@ int pg_engine::vq_encode(const void* img, int img_dtype, int64_t* idx, int B, hi
     return PG_OK;
 }
 
+// =============================================================================== SigLIP + aligner
+template <typename T>
+void pg_engine::lin(hipStream_t s, const LinW& l, const T* in, void* out, int out_f32, const void* residual, int res_f32, int act, long M) {
+    GemmA a; a.ptr = in; a.lda = l.in;
+    GemmEpi e; e.out = out; e.out_f32 = out_f32; e.ldc = l.out; e.bias_n = l.b; e.residual = residual; e.res_f32 = res_f32; e.act = act;
+    launch_gemm<T>(s, a, (const T*)l.w, l.in, 0, e, (int)M, l.out, l.in, 1);
+}
+template <typename T>
+int pg_engine::vision_encode(const void* img, int img_dtype, void* out, int out_dtype, int B, hipStream_t s) {
+    if (!finalized) FAIL(PG_ERR_STATE, "pg_finalize_weights not called");
+    if (!cfg.with_vision) FAIL(PG_ERR_STATE, "engine created without the vision encoder");
+    if (B < 1 || B > cfg.max_vision_images) FAIL(PG_ERR_CAPACITY, "images %d > max_vision_images %d", B, cfg.max_vision_images);
+    if (out_dtype != PG_F32 && !bf) FAIL(PG_ERR_ARG, "bf16 output needs the bf16 engine");
+    HIPCHK(hipSetDevice(dev));
+    const int C = cfg.vit_width, ps = cfg.vit_patch, g = cfg.vit_img / ps, P = g * g, NH = cfg.vit_heads;
+    const long M = (long)B * P;
+    // PatchEmbed conv16x16/s16 as a GEMM over gathered patches, + bias, + learned pos-embed (no cls token)
+    launch_patchify<T>(s, img, img_dtype == PG_BF16, (T*)vt, B, cfg.vit_img, ps);
+    lin<T>(s, vit_patch, (const T*)vt, vx, 1, nullptr, 0, 0, M);
+    launch_add_pos(s, vx, vit_pos, B, P, C);
+    const float scale = 1.0f / sqrtf(64.0f);
+    for (const VitBlockW& w : vit_blocks) {
+        launch_layernorm<T>(s, vx, w.n1.g, w.n1.b, (T*)vt, (int)M, C, 1e-6f);
+        {   // q | k = t . Wqk^T + b  ([M, 2C]); V^T[b] = Wv . t[b]^T + bv ([C, P], operands swapped)
+            GemmA a; a.ptr = vt; a.lda = C;
+            GemmEpi e; e.out = vqk; e.out_f32 = 0; e.ldc = 2 * C; e.bias_n = w.qkv.b;
+            launch_gemm<T>(s, a, (const T*)w.qkv.w, C, 0, e, (int)M, 2 * C, C, 1);
+            GemmA av; av.ptr = (const T*)w.qkv.w + (long)2 * C * C; av.lda = C;
+            GemmEpi ev; ev.out = vvt; ev.out_f32 = 0; ev.ldc = P; ev.strideC = (long)C * P; ev.bias_m = w.qkv.b + 2 * C;
+            launch_gemm<T>(s, av, (const T*)vt, C, (long)P * C, ev, C, P, C, B);
+        }
+        {   // scores[b,h] = q[b,:,h] . k[b,:,h]^T / sqrt(64)   (non-causal SDPA, siglip_vit.py:178-183)
+            GemmA a; a.ptr = vqk; a.lda = 2 * C; a.strideA = (long)P * 2 * C; a.strideA2 = 64;
+            GemmEpi e; e.out = vscore; e.out_f32 = 1; e.ldc = P; e.strideC = (long)NH * P * P; e.strideC2 = (long)P * P;
+            launch_gemm<T>(s, a, (const T*)vqk + C, 2 * C, (long)P * 2 * C, e, P, P, 64, B, NH, 64);
+        }
+        launch_softmax_rows<T>(s, vscore, (T*)vp, (int)(B * NH * P), P, scale);
+        {   // o[b,:,h] = P[b,h] . V^T[b][h*64..]^T
+            GemmA a; a.ptr = vp; a.lda = P; a.strideA = (long)NH * P * P; a.strideA2 = (long)P * P;
+            GemmEpi e; e.out = vo; e.out_f32 = 0; e.ldc = C; e.strideC = (long)P * C; e.strideC2 = 64;
+            launch_gemm<T>(s, a, (const T*)vvt, P, (long)C * P, e, P, 64, P, B, NH, (long)64 * P);
+        }
+        lin<T>(s, w.proj, (const T*)vo, vx, 1, vx, 1, 0, M);                      // x += proj(o)
+        launch_layernorm<T>(s, vx, w.n2.g, w.n2.b, (T*)vt, (int)M, C, 1e-6f);
+        lin<T>(s, w.fc1, (const T*)vt, vh, 0, nullptr, 0, 1, M);                    // GELU(erf)
+        lin<T>(s, w.fc2, (const T*)vh, vx, 1, vx, 1, 0, M);                        // x += fc2(.)
+    }
+    launch_layernorm<T>(s, vx, vit_norm.g, vit_norm.b, (T*)vt, (int)M, C, 1e-6f);
+    lin<T>(s, al0, (const T*)vt, val, 0, nullptr, 0, 1, M);                         // aligner: Linear -> GELU -> Linear
+    lin<T>(s, al2, (const T*)val, out, out_dtype == PG_F32 ? 1 : 0, nullptr, 0, 0, M);
+    HIPCHK(hipGetLastError());
+    return PG_OK;
+}
+
 int pg_engine::fetch_timing() {
     if (have_decode_t) { HIPCHK(hipEventSynchronize(ev_t1)); HIPCHK(hipEventElapsedTime(&timing.decode_ms, ev_t0, ev_t1)); have_decode_t = false; }
     if (have_prefill_t) { HIPCHK(hipEventSynchronize(ev_p1)); HIPCHK(hipEventElapsedTime(&timing.prefill_ms, ev_p0, ev_p1)); have_prefill_t = false; }
@@ -1077,6 +1188,11 @@ int pg_vq_encode(pg_handle h, const void* img_dev, int img_dtype, int64_t* idx_o
     if (!h || !img_dev || !idx_out_dev) return PG_ERR_ARG;
     return h->bf ? h->vq_encode<bf16>(img_dev, img_dtype, idx_out_dev, B, (hipStream_t)s)
                  : h->vq_encode<float>(img_dev, img_dtype, idx_out_dev, B, (hipStream_t)s);
+}
+int pg_vision_encode(pg_handle h, const void* img_dev, int img_dtype, void* out_dev, int out_dtype, int B, pg_stream s) {
+    if (!h || !img_dev || !out_dev) return PG_ERR_ARG;
+    return h->bf ? h->vision_encode<bf16>(img_dev, img_dtype, out_dev, out_dtype, B, (hipStream_t)s)
+                 : h->vision_encode<float>(img_dev, img_dtype, out_dev, out_dtype, B, (hipStream_t)s);
 }
 int pg_get_timing(pg_handle h, pg_timing* out) {
     if (!h || !out) return PG_ERR_ARG;

@@ -72,18 +72,18 @@ struct ConvLoader {
 template <typename T>
 struct Epi {
     GemmEpi e; int M, N;
-    __device__ __forceinline__ void operator()(int batch, int row, int col, float v) const {
+    __device__ __forceinline__ void operator()(long coff, long roff, int row, int col, float v) const {
         if (row >= M || col >= N) return;
         v *= e.scale;
         if (e.bias_n) v += e.bias_n[col];
         if (e.bias_m) v += e.bias_m[row];
         if (e.residual) {
             const long ldr = e.ldr ? e.ldr : e.ldc;
-            const long ro = (long)batch * e.strideR + (long)row * ldr + col;
+            const long ro = roff + (long)row * ldr + col;
             v += e.res_f32 ? ((const float*)e.residual)[ro] : ET<T>::ld((const T*)e.residual + ro);
         }
         if (e.act == 1) v = gelu_erf(v);
-        const long o = (long)batch * e.strideC + (long)row * e.ldc + col;
+        const long o = coff + (long)row * e.ldc + col;
         if (e.out_f32) ((float*)e.out)[o] = v; else ET<T>::st((T*)e.out + o, v);
     }
 };
@@ -105,11 +105,13 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
 
 template <class AL, class EP>
 __global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __restrict__ W, long ldb,
-                                                         long strideA, long strideB, EP ep, int M, int N,
-                                                         int K, int ntm, int ntn) {
+                                                         long strideA, long strideB, long strideA2, long strideB2, EP ep,
+                                                         int M, int N, int K, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int batch = blockIdx.y;
+    const int batch = blockIdx.y, batch2 = blockIdx.z;
+    const long coff = (long)batch * ep.e.strideC + (long)batch2 * ep.e.strideC2;
+    const long roff = (long)batch * ep.e.strideR;
     // XCD-aware tile order: each XCD (blockIdx % 8) owns a contiguous run of tiles; inside
     // the run tiles are grouped 8(M) x 8(N) so concurrently resident blocks share A and W panels in L2.
     const int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -121,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __r
     } else { tile_m = t % ntm; tile_n = t / ntm; }
     const int m0 = tile_m * BIG_BM, n0 = tile_n * BIG_BN;
 
-    al.A_offset(strideA * batch);
-    const bf16* Wb = W + strideB * batch;
+    al.A_offset(strideA * batch + strideA2 * batch2);
+    const bf16* Wb = W + strideB * batch + strideB2 * batch2;
     // staging assignment: wave w, instruction i covers tile rows (w*4+i)*8 .. +7, lane -> (row l>>3, chunk l&7)
     const bf16* wrow[4]; int sc[4];
 #pragma unroll
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __r
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                ep(batch, m0 + wm * 64 + mt * 16 + g * 4 + r, n0 + wn * 64 + nt * 16 + lr, acc[mt][nt][r]);
+                ep(coff, roff, m0 + wm * 64 + mt * 16 + g * 4 + r, n0 + wn * 64 + nt * 16 + lr, acc[mt][nt][r]);
 }
 
 // loaders need a batch offset hook
@@ -206,14 +208,17 @@ template <typename T> struct ConvLoaderB : ConvLoader<T> {
 // ------------------------------------------------------------------------------- fp32 GEMM
 template <class AL, class EP>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(AL al, const float* __restrict__ W, long ldb,
-                                                      long strideA, long strideB, EP ep, int M, int N, int K) {
+                                                      long strideA, long strideB, long strideA2, long strideB2, int nbatch, EP ep,
+                                                      int M, int N, int K) {
     __shared__ float As[16][68];
     __shared__ float Bs[16][68];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int batch = blockIdx.z;
+    const int batch = blockIdx.z % nbatch, batch2 = blockIdx.z / nbatch;
+    const long coff = (long)batch * ep.e.strideC + (long)batch2 * ep.e.strideC2;
+    const long roff = (long)batch * ep.e.strideR;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    al.A_offset(strideA * batch);
-    const float* Wb = W + strideB * batch;
+    al.A_offset(strideA * batch + strideA2 * batch2);
+    const float* Wb = W + strideB * batch + strideB2 * batch2;
     float acc[4][4] = {};
     for (int k0 = 0; k0 < K; k0 += 16) {
 #pragma unroll
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(AL al, const float* __res
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ep(batch, m0 + ty * 4 + i, n0 + tx * 4 + j, acc[i][j]);
+        for (int j = 0; j < 4; ++j) ep(coff, roff, m0 + ty * 4 + i, n0 + tx * 4 + j, acc[i][j]);
 }
 
 // ------------------------------------------------------------------------------- launchers
@@ -247,16 +252,16 @@ template <typename T> struct BigDispatch;
 
 template <> struct BigDispatch<bf16> {
     static void run(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e,
-                    int M, int N, int K, int batch) {
+                    int M, int N, int K, int batch, int batch2, long strideB2) {
         Epi<bf16> ep{e, M, N};
         const int ntm = (M + BIG_BM - 1) / BIG_BM, ntn = (N + BIG_BN - 1) / BIG_BN;
-        dim3 grid(ntm * ntn, batch), block(256);
+        dim3 grid(ntm * ntn, batch, batch2), block(256);
         if (a.kind == 0) {
             PlainLoaderB<bf16> al; al.A = (const bf16*)a.ptr; al.lda = a.lda; al.M = M;
             auto kfn = gemm_big_kernel<PlainLoaderB<bf16>, Epi<bf16>>;
             static bool attr = false;
             if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS); attr = true; }
-            hipLaunchKernelGGL(kfn, grid, block, BIG_LDS, s, al, W, ldb, a.strideA, strideB, ep, M, N, K, ntm, ntn);
+            hipLaunchKernelGGL(kfn, grid, block, BIG_LDS, s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, ntm, ntn);
         } else {
             ConvLoaderB<bf16> al; al.X = (const bf16*)a.ptr; al.zeros = (const bf16*)a.zeros;
             al.Hi = a.Hi; al.Wi = a.Wi; al.Cin = a.Cin; al.up = a.up; al.stride2 = (a.kind == 2);
@@ -264,38 +269,38 @@ template <> struct BigDispatch<bf16> {
             auto kfn = gemm_big_kernel<ConvLoaderB<bf16>, Epi<bf16>>;
             static bool attr = false;
             if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS); attr = true; }
-            hipLaunchKernelGGL(kfn, grid, block, BIG_LDS, s, al, W, ldb, a.strideA, strideB, ep, M, N, K, ntm, ntn);
+            hipLaunchKernelGGL(kfn, grid, block, BIG_LDS, s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, ntm, ntn);
         }
     }
 };
 
 template <> struct BigDispatch<float> {
     static void run(hipStream_t s, const GemmA& a, const float* W, long ldb, long strideB, const GemmEpi& e,
-                    int M, int N, int K, int batch) {
+                    int M, int N, int K, int batch, int batch2, long strideB2) {
         Epi<float> ep{e, M, N};
-        dim3 grid((N + 63) / 64, (M + 63) / 64, batch), block(256);
+        dim3 grid((N + 63) / 64, (M + 63) / 64, batch * batch2), block(256);
         if (a.kind == 0) {
             PlainLoaderB<float> al; al.A = (const float*)a.ptr; al.lda = a.lda; al.M = M;
             hipLaunchKernelGGL((gemm_f32_kernel<PlainLoaderB<float>, Epi<float>>), grid, block, 0, s, al, W, ldb,
-                               a.strideA, strideB, ep, M, N, K);
+                               a.strideA, strideB, a.strideA2, strideB2, batch, ep, M, N, K);
         } else {
             ConvLoaderB<float> al; al.X = (const float*)a.ptr; al.zeros = (const float*)a.zeros;
             al.Hi = a.Hi; al.Wi = a.Wi; al.Cin = a.Cin; al.up = a.up; al.stride2 = (a.kind == 2);
             al.Ho = al.stride2 ? a.Hi / 2 : (a.Hi << a.up); al.Wo = al.stride2 ? a.Wi / 2 : (a.Wi << a.up); al.M = M;
             hipLaunchKernelGGL((gemm_f32_kernel<ConvLoaderB<float>, Epi<float>>), grid, block, 0, s, al, W, ldb,
-                               a.strideA, strideB, ep, M, N, K);
+                               a.strideA, strideB, a.strideA2, strideB2, batch, ep, M, N, K);
         }
     }
 };
 
 template <typename T>
 void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strideB, const GemmEpi& e,
-                 int M, int N, int K, int batch) {
+                 int M, int N, int K, int batch, int batch2, long strideB2) {
     if (M <= 0 || N <= 0) return;
-    BigDispatch<T>::run(s, a, W, ldb, strideB, e, M, N, K, batch);
+    BigDispatch<T>::run(s, a, W, ldb, strideB, e, M, N, K, batch, batch2, strideB2);
 }
-template void launch_gemm<float>(hipStream_t, const GemmA&, const float*, long, long, const GemmEpi&, int, int, int, int);
-template void launch_gemm<bf16>(hipStream_t, const GemmA&, const bf16*, long, long, const GemmEpi&, int, int, int, int);
+template void launch_gemm<float>(hipStream_t, const GemmA&, const float*, long, long, const GemmEpi&, int, int, int, int, int, long);
+template void launch_gemm<bf16>(hipStream_t, const GemmA&, const bf16*, long, long, const GemmEpi&, int, int, int, int, int, long);
 
 // ------------------------------------------------------------------------------- skinny GEMM
 #define SK_BK 128

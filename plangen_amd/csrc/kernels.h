@@ -16,6 +16,7 @@ struct GemmA {
     int kind = 0;
     const void* ptr = nullptr;
     long lda = 0, strideA = 0;          // strideA: per-batch (blockIdx.y) element stride
+    long strideA2 = 0;                  // second batch dimension (e.g. attention heads)
     int Hi = 0, Wi = 0, Cin = 0, up = 0;
     const void* zeros = nullptr;        // >= 256 B of zeros (conv halo source)
 };
@@ -23,7 +24,7 @@ struct GemmA {
 struct GemmEpi {
     void* out = nullptr;
     int out_f32 = 1;                    // 1: float* out, 0: T* out
-    long ldc = 0, strideC = 0;
+    long ldc = 0, strideC = 0, strideC2 = 0;
     const float* bias_n = nullptr;
     const float* bias_m = nullptr;
     const void* residual = nullptr;     // T (or fp32 when res_f32), same ldc/stride layout as out unless ldr set
@@ -34,7 +35,7 @@ struct GemmEpi {
 };
 template <typename T>
 void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strideB,
-                 const GemmEpi& e, int M, int N, int K, int batch);
+                 const GemmEpi& e, int M, int N, int K, int batch, int batch2 = 1, long strideB2 = 0);
 
 // Skinny weight-streaming GEMM (decode): x [M,K] bf16 (M <= 128 per launch block-row),
 // W [N,K] bf16, out fp32 [S,M,N] split-K partial slabs (consumer kernels reduce over S).
@@ -150,6 +151,16 @@ void launch_conv3x3_in(hipStream_t s, const void* x, int x_bf16, const float* w 
                        const float* bias, T* out, int B, int H, int W, int Cin, int Cout);
 // nearest-code argmin: z fp32 [n, D] (D<=8) vs L2-normalised codebook fp32 [V, D] -> int64 idx
 void launch_vq_argmin(hipStream_t s, const float* z, const float* codebook, int64_t* idx, int n, int D, int V);
+
+// ---------------------------------------------------------------- SigLIP (a13)
+// LayerNorm over the last dim of fp32 rows -> T
+template <typename T>
+void launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, T* y, int M, int C, float eps);
+// non-overlapping patches of NCHW images -> T [B*P, 3*ps*ps] with k = (c, py, px) (Conv2d weight order)
+template <typename T>
+void launch_patchify(hipStream_t s, const void* img, int img_bf16, T* out, int B, int S, int ps);
+// x[b, p, :] += pos[p, :]
+void launch_add_pos(hipStream_t s, float* x, const float* pos, int B, int P, int C);
 
 // ---------------------------------------------------------------- weight conversion
 // dst (T) [rows, cols] at row offset <- src fp32/bf16 [rows, cols] (device staging)

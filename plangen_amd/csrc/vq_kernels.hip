@@ -312,3 +312,56 @@ void launch_vq_argmin(hipStream_t s, const float* z, const float* codebook, int6
     if (n <= 0) return;
     hipLaunchKernelGGL(vq_argmin_kernel, dim3(n), dim3(256), 0, s, z, codebook, idx, D, V);
 }
+
+// ------------------------------------------------------------------------------- SigLIP helpers
+// LayerNorm(eps) over the last dim: fp32 rows in, T out (siglip_vit.py Block.norm1/norm2, final norm).
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* __restrict__ y, int C, float eps) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + (long)m * C;
+    float s = 0.f;
+    for (int i = tid; i < C; i += 256) s += xr[i];
+    const float mean = block_sum<4>(s, red) / (float)C;
+    float q = 0.f;
+    for (int i = tid; i < C; i += 256) { const float d = xr[i] - mean; q = fmaf(d, d, q); }
+    const float rstd = rsqrtf(block_sum<4>(q, red) / (float)C + eps);
+    for (int i = tid; i < C; i += 256) ET<T>::st(y + (long)m * C + i, (xr[i] - mean) * rstd * gamma[i] + beta[i]);
+}
+template <typename T>
+void launch_layernorm(hipStream_t s, const float* x, const float* gamma, const float* beta, T* y, int M, int C, float eps) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(layernorm_kernel<T>, dim3(M), dim3(256), 0, s, x, gamma, beta, y, C, eps);
+}
+template void launch_layernorm<float>(hipStream_t, const float*, const float*, const float*, float*, int, int, float);
+template void launch_layernorm<bf16>(hipStream_t, const float*, const float*, const float*, bf16*, int, int, float);
+
+// PatchEmbed's Conv2d(3, C, ps, stride ps) as a GEMM: patches [B*P, 3*ps*ps], k = (c, py, px).
+template <typename T>
+__global__ void patchify_kernel(const void* __restrict__ img, int img_bf16, T* __restrict__ out, int S, int ps) {
+    const int g = S / ps, K = 3 * ps * ps;
+    const int row = blockIdx.x;                       // b*P + p
+    const int b = row / (g * g), p = row % (g * g), py0 = (p / g) * ps, px0 = (p % g) * ps;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int c = k / (ps * ps), r = k % (ps * ps), py = r / ps, px = r % ps;
+        const long si = (((long)b * 3 + c) * S + py0 + py) * S + px0 + px;
+        const float v = img_bf16 ? ET<bf16>::ld((const bf16*)img + si) : ((const float*)img)[si];
+        ET<T>::st(out + (long)row * K + k, v);
+    }
+}
+template <typename T>
+void launch_patchify(hipStream_t s, const void* img, int img_bf16, T* out, int B, int S, int ps) {
+    const int g = S / ps;
+    hipLaunchKernelGGL(patchify_kernel<T>, dim3(B * g * g), dim3(256), 0, s, img, img_bf16, out, S, ps);
+}
+template void launch_patchify<float>(hipStream_t, const void*, int, float*, int, int, int);
+template void launch_patchify<bf16>(hipStream_t, const void*, int, bf16*, int, int, int);
+
+__global__ void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, int P, int C) {
+    const int row = blockIdx.x, p = row % P;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) x[(long)row * C + i] += pos[(long)p * C + i];
+}
+void launch_add_pos(hipStream_t s, float* x, const float* pos, int B, int P, int C) {
+    hipLaunchKernelGGL(add_pos_kernel, dim3(B * P), dim3(256), 0, s, x, pos, P, C);
+}

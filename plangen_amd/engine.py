@@ -40,7 +40,8 @@ class Engine:
 
     def __init__(self, cfg: PlanGenConfig, dtype: str = "bf16", max_rows: int = 16, max_prompt: int = 256,
                  max_new: Optional[int] = None, max_images: Optional[int] = None, with_lm_head: bool = False,
-                 with_vq_encoder: bool = False, device: int = 0):
+                 with_vq_encoder: bool = False, with_vision: bool = False, max_vision_images: Optional[int] = None,
+                 device: int = 0):
         if not torch.cuda.is_available():
             raise PlanGenError("plangen_amd.Engine needs an MI355X (no CPU fallback)")
         self.lib = _lib.load()
@@ -65,6 +66,10 @@ class Engine:
         c.max_rows, c.max_prompt, c.max_new, c.max_images = max_rows, max_prompt, self.max_new, self.max_images
         c.with_lm_head = int(with_lm_head)
         c.with_vq_encoder = int(with_vq_encoder)
+        c.with_vision = int(with_vision)
+        for k in ("vit_width", "vit_layers", "vit_heads", "vit_mlp", "vit_patch", "vit_img"):
+            setattr(c, k, int(getattr(cfg, k)))
+        c.max_vision_images = max_vision_images if max_vision_images is not None else self.max_images
         self._c = c
         h = C.c_void_p()
         rc = self.lib.pg_create(C.byref(h), C.byref(c), device)
@@ -241,6 +246,22 @@ class Engine:
             norm(E + "norm_out", b_in)
             conv(E + "conv_out", cfg.vq_z, b_in, 3)
             conv(V + "quant_conv", cfg.img_dim, cfg.vq_z, 1)
+        if self._c.with_vision:
+            Cw, Mh, ps = cfg.vit_width, cfg.vit_mlp, cfg.vit_patch
+            VT = "vision_model.vision_tower."
+
+            def lin(name, o, i):
+                load(name + ".weight", nrm(o, i)); load(name + ".bias", nrm(o))
+
+            load(VT + "patch_embed.proj.weight", nrm(Cw, 3, ps, ps, s=1.0 / math.sqrt(3 * ps * ps)))
+            load(VT + "patch_embed.proj.bias", nrm(Cw))
+            load(VT + "pos_embed", nrm(1, cfg.vit_tokens, Cw))
+            for i in range(cfg.vit_layers):
+                b = f"{VT}blocks.{i}."
+                norm(b + "norm1", Cw); lin(b + "attn.qkv", 3 * Cw, Cw); lin(b + "attn.proj", Cw, Cw)
+                norm(b + "norm2", Cw); lin(b + "mlp.fc1", Mh, Cw); lin(b + "mlp.fc2", Cw, Mh)
+            norm(VT + "norm", Cw)
+            lin("aligner.layers.0", H, Cw); lin("aligner.layers.2", H, H)
         missing = C.c_int(0)
         self._check(self.lib.pg_finalize_weights(self.h, C.byref(missing), self.stream), "pg_finalize_weights")
         if missing.value:
@@ -348,6 +369,16 @@ class Engine:
         out = torch.empty((B * self.cfg.img_tokens,), dtype=torch.int64, device=self.device)
         self._check(self.lib.pg_vq_encode(self.h, self._p(img), _dt(img), self._p(out), B, self.stream), "pg_vq_encode")
         self._keep = [img]
+        return out
+
+    def vision_encode(self, images: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+        """aligner(vision_model(images)): [B,3,S,S] -> [B, P, hidden] (modeling_vlm.py:243-250)."""
+        images = self._dev(images)
+        B = images.shape[0]
+        out = torch.empty((B, self.cfg.vit_tokens, self.cfg.hidden), dtype=dtype, device=self.device)
+        self._check(self.lib.pg_vision_encode(self.h, self._p(images), _dt(images), self._p(out), _dt(out), B, self.stream),
+                    "pg_vision_encode")
+        self._keep = [images]
         return out
 
     # ------------------------------------------------------------------ test taps

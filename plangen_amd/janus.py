@@ -143,6 +143,21 @@ class MultiModalityCausalLM:
     def prepare_gen_img_embeds(self, image_ids: torch.Tensor) -> torch.Tensor:
         return self.engine.gen_embed(image_ids)
 
+    def prepare_inputs_embeds(self, input_ids: torch.Tensor, pixel_values: torch.Tensor,
+                              images_seq_mask: torch.Tensor, images_emb_mask: torch.Tensor, **kwargs) -> torch.Tensor:
+        """MultiModalityCausalLM.prepare_inputs_embeds (modeling_vlm.py:221-268): SigLIP + aligner on
+        the device, then the masked scatter of the image embeddings into the text embeddings."""
+        bs, n = pixel_values.shape[0:2]
+        images = pixel_values.reshape(bs * n, *pixel_values.shape[2:])
+        images_embeds = self.engine.vision_encode(images)                   # [b*n, T2, D]
+        images_embeds = images_embeds.reshape(bs, n * images_embeds.shape[1], -1)
+        images_emb_mask = images_emb_mask.reshape(bs, -1).to(self.engine.device).bool()
+        ids = input_ids.to(self.engine.device).clone()
+        ids[ids < 0] = 0
+        inputs_embeds = self.language_model.get_input_embeddings()(ids)
+        inputs_embeds[images_seq_mask.to(self.engine.device).bool()] = images_embeds[images_emb_mask].to(inputs_embeds.dtype)
+        return inputs_embeds
+
     def eval(self):
         self.training = False
         return self

@@ -35,7 +35,7 @@ def ocfg(tiny_cfg):
 def tiny_weights(ocfg):
     """Seeded weights, identical to the ones the golden fixtures were generated with."""
     from oracle.ref_cpu import make_weights
-    return make_weights(ocfg, seed=1, with_encoder=True)
+    return make_weights(ocfg, seed=1, with_encoder=True, with_vision=True)
 
 
 def wsum(W):
@@ -50,8 +50,8 @@ def get_engine(tiny_cfg, tiny_weights, dtype, **kw):
     from plangen_amd.engine import Engine
     key = (dtype, tuple(sorted(kw.items())))
     if key not in _ENGINES:
-        args = dict(max_rows=8, max_prompt=32, max_new=tiny_cfg.img_tokens, max_images=4, with_lm_head=True,
-                    with_vq_encoder=True)
+        args = dict(max_rows=8, max_prompt=96, max_new=tiny_cfg.img_tokens, max_images=4, with_lm_head=True,
+                    with_vq_encoder=True, with_vision=True)
         args.update(kw)
         e = Engine(tiny_cfg, dtype=dtype, **args)
         e.load_state_dict(tiny_weights)

@@ -53,7 +53,7 @@ def test_kv_cache_matches_oracle(tiny_cfg, tiny_weights, ocfg):
     e.prefill(ids, pad, position_mode=0)
     pos = torch.arange(L)[None].expand(ids.shape[0], -1)
     _, cache = R.llama_forward(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, pos)
-    slots = 32 + tiny_cfg.img_tokens
+    slots = 96 + tiny_cfg.img_tokens
     for layer in range(tiny_cfg.n_layers):
         for name, ref in (("kcache", cache.k[layer]), ("vcache", cache.v[layer])):
             buf = e.debug_read(name, layer, 8 * tiny_cfg.n_heads * slots * 128, torch.float32).cpu()
@@ -224,3 +224,45 @@ def test_sampling_is_seeded_and_follows_softmax(tiny_cfg, tiny_weights):
         top = p[b].topk(5).indices
         emp = torch.stack([(draws[:, b] == t).float().mean() for t in top])
         assert (emp - p[b][top]).abs().max() < 0.12
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("bf16", 6e-2)])
+def test_vision_encoder_matches_oracle(tiny_cfg, tiny_weights, ocfg, dtype, tol):
+    """SigLIP + aligner (a13).  Oracle = restatement of siglip_vit.py / clip_encoder.py
+    (parity unpinned: timm absent, see oracle/ref_cpu.py)."""
+    e = get_engine(tiny_cfg, tiny_weights, dtype)
+    g = torch.Generator().manual_seed(31)
+    img = torch.rand(3, 3, tiny_cfg.vit_img, tiny_cfg.vit_img, generator=g) * 2 - 1
+    ref = R.vision_encode(tiny_weights, ocfg, img)
+    out = e.vision_encode(img).cpu()
+    assert out.shape == ref.shape == (3, tiny_cfg.vit_tokens, tiny_cfg.hidden)
+    assert (out - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+
+
+def test_mmu_path_prepare_inputs_embeds_then_generate(tiny_cfg, tiny_weights, ocfg):
+    """task_type='mmu' (plangen_base.py:365-366, :513-523): image -> SigLIP -> scatter into the text
+    embeddings -> greedy text decode; ids bit-exact vs the oracle in fp32."""
+    from plangen_amd.system import System
+    e = get_engine(tiny_cfg, tiny_weights, "f32")
+    sysm = System(tiny_cfg, e)
+    g = torch.Generator().manual_seed(32)
+    B, P = 2, tiny_cfg.vit_tokens
+    Ltxt = [5, 3]
+    L = P + max(Ltxt) + 2
+    ids = torch.full((B, L), tiny_cfg.pad_id, dtype=torch.int64)
+    seq_mask = torch.zeros((B, L), dtype=torch.bool)
+    attn = torch.zeros((B, L), dtype=torch.int32)
+    for b in range(B):
+        n = 1 + P + Ltxt[b] + 1
+        row = torch.randint(8, tiny_cfg.vocab, (n,), generator=g)
+        ids[b, L - n:] = row
+        seq_mask[b, L - n + 1: L - n + 1 + P] = True          # image placeholder slots
+        attn[b, L - n:] = 1
+    pix = torch.rand(B, 1, 3, tiny_cfg.vit_img, tiny_cfg.vit_img, generator=g) * 2 - 1
+    emb_mask = torch.ones((B, 1, P), dtype=torch.bool)
+    ref_emb = R.prepare_inputs_embeds(tiny_weights, ocfg, ids, pix, seq_mask, emb_mask)
+    emb = sysm.vl_gpt.prepare_inputs_embeds(input_ids=ids, pixel_values=pix, images_seq_mask=seq_mask, images_emb_mask=emb_mask)
+    assert (emb.cpu() - ref_emb).abs().max() < 2e-4
+    ref = R.generate_text_greedy(tiny_weights, ocfg, ref_emb, attn, 8, tiny_cfg.eos_id)
+    out = sysm.x2t(emb, attn.to(e.device), max_new_tokens=8)
+    assert np.array_equal(out.cpu().numpy(), ref.numpy())
