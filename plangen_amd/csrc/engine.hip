@@ -67,7 +67,9 @@ struct pg_engine {
     std::map<std::string, Slot> slots_map;
 
     // ---- weights
-    struct Layer { void *wqkv, *wo, *wgu, *wd, *ln1, *ln2; };
+    struct Layer { void *wqkv, *wo, *wgu, *wd, *ln1, *ln2; void *wqkv_t = nullptr, *wo_t = nullptr, *wgu_t = nullptr, *wd_t = nullptr; };
+    void *gh_w1_t = nullptr, *gh_w2_t = nullptr, *lm_head_t = nullptr;
+    int tile_one(hipStream_t s, const void* src, void** dst, int N, int K);
     std::vector<Layer> layers;
     void* norm_w = nullptr; float* embed = nullptr; void* lm_head = nullptr;
     void *gh_w1 = nullptr, *gh_w2 = nullptr; float *gh_b1 = nullptr, *gh_b2 = nullptr;
@@ -98,7 +100,7 @@ struct pg_engine {
     void* kv = nullptr;
     // ---- workspaces
     long max_tok = 0;
-    float* x = nullptr; void* xn = nullptr; float* part = nullptr; long part_elems = 0;
+    float* x = nullptr; void* xn = nullptr; float* part = nullptr; long part_elems = 0, decode_part_elems = 0;
     void *qbuf = nullptr, *obuf = nullptr, *hbuf = nullptr, *hfin = nullptr, *gh_in = nullptr, *gh_mid = nullptr;
     // VQ: cur / t1 / t2 / t3 rotate through vbuf
     void* vbuf[4] = {nullptr, nullptr, nullptr, nullptr}; long vbuf_elems = 0;
@@ -129,9 +131,14 @@ struct pg_engine {
     int img_tokens() const { return cfg.grid * cfg.grid; }
     int img_size() const { return cfg.grid << (cfg.vq_levels - 1); }
     size_t kv_layer_elems() const { return (size_t)cfg.max_rows * cfg.n_heads * slots * 128; }
-    void* kc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 0) * kv_layer_elems() * esz; }
-    void* vc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 1) * kv_layer_elems() * esz; }
+    void* kc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 0) * kv_layer_elems() * esz + kv_row_off; }
+    void* vc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 1) * kv_layer_elems() * esz + kv_row_off; }
     int shared_len = 0, shared_row = 1; bool share_uncond = true;
+    // decode lanes: the batch's rows split into independent chains on separate streams
+    size_t kv_row_off = 0;            // byte offset of the current lane's first row inside a K or V layer block
+    int h_len_off = 0; int lanes_opt = -1;   // -1 auto, 1, 2
+    float* part2 = nullptr; hipStream_t istream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int32_t* d_ndec2 = nullptr;
     SeqState seq() const { return SeqState{d_len, d_pos_off, d_ndec, d_tok_row, d_tok_j, shared_len, shared_row}; }
 
     int create();
@@ -149,7 +156,7 @@ struct pg_engine {
     int finalize(int* missing, hipStream_t s);
     int prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtype, const int32_t* pad_len, int R_, int L_,
                 int pmode, void* hidden_out, int hidden_dtype, hipStream_t s);
-    template <typename T> void gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, int K, bool allow_skinny);
+    template <typename T> void gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, int K, bool allow_skinny, const void* Wt = nullptr);
     template <typename T> void run_layers(hipStream_t s, int M, int mode, T* final_out);
     template <typename T> void head_logits(hipStream_t s, const T* in, int M);
     void forward_decode(hipStream_t s);
@@ -429,7 +436,8 @@ int pg_engine::create() {
         const long rows = cfg.max_rows;
         long need = 0;
         auto upd = [&](long N, long K) {
-            for (long mc : {16L, 32L, 64L, 128L, rows}) {
+            for (long mc : {16L, 32L, 48L, 64L, 96L, 128L, 192L, 256L, rows, rows / 2}) {
+                if (mc < 1) continue;
                 const long m = mc < rows ? mc : rows;
                 const long S = (K % 128 == 0) ? skinny_pick_splits((int)N, (int)K, (int)m) : 1;
                 if (S * m * N > need) need = S * m * N;
@@ -438,8 +446,12 @@ int pg_engine::create() {
         upd(3L * HDm, Hh); upd(Hh, HDm); upd(2L * I, Hh); upd(Hh, I); upd(G, Hh); upd(V, G);
         if (cfg.with_lm_head) upd(cfg.vocab, Hh);
         if (need > part_elems) part_elems = need;
+        decode_part_elems = need;
     }
     TRY(dalloc(&part, (size_t)part_elems * 4));
+    TRY(dalloc(&part2, (size_t)decode_part_elems * 4));
+    TRY(dalloc(&d_ndec2, 64));
+    HIPCHK(hipMemset(d_ndec2, 0, 64));
     TRY(dalloc(&qbuf, (size_t)max_tok * HDm * esz));
     TRY(dalloc(&obuf, (size_t)max_tok * HDm * esz));
     TRY(dalloc(&hbuf, (size_t)max_tok * I * esz));
@@ -473,6 +485,9 @@ int pg_engine::create() {
         if (cfg.with_vq_encoder) TRY(dalloc(&enc_z, (size_t)cfg.max_images * g2 * 8 * 4));
     }
     HIPCHK(hipStreamCreateWithFlags(&istream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&istream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&ev_t0)); HIPCHK(hipEventCreate(&ev_t1));
@@ -491,7 +506,8 @@ void pg_engine::destroy() {
     if (stage_dev) (void)hipFree(stage_dev);
     if (h_stage) (void)hipHostFree(h_stage);
     for (hipEvent_t e : attn_ev) (void)hipEventDestroy(e);
-    hipEvent_t evs[] = {ev_in, ev_out, ev_t0, ev_t1, ev_p0, ev_p1, ev_v0, ev_v1};
+    hipEvent_t evs[] = {ev_in, ev_out, ev_t0, ev_t1, ev_p0, ev_p1, ev_v0, ev_v1, ev_fork, ev_join};
+    if (istream2) (void)hipStreamDestroy(istream2);
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     if (istream) (void)hipStreamDestroy(istream);
 }
@@ -583,21 +599,40 @@ int pg_engine::finalize(int* missing, hipStream_t s) {
         HIPCHK(hipMemcpy(cos_t, c.data(), c.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(sin_t, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
     }
+    if (bf) {   // decode copies of the GEMM weights in the tiled layout (contiguous 1 KiB per wave load)
+        const int Hh2 = H(), I = cfg.inter, HDm = HD();
+        for (Layer& ly : layers) {
+            TRY(tile_one(s, ly.wqkv, &ly.wqkv_t, 3 * HDm, Hh2));
+            TRY(tile_one(s, ly.wo, &ly.wo_t, Hh2, HDm));
+            TRY(tile_one(s, ly.wgu, &ly.wgu_t, 2 * I, Hh2));
+            TRY(tile_one(s, ly.wd, &ly.wd_t, Hh2, I));
+        }
+        TRY(tile_one(s, gh_w1, &gh_w1_t, cfg.gen_head_dim, Hh2));
+        TRY(tile_one(s, gh_w2, &gh_w2_t, cfg.img_vocab, cfg.gen_head_dim));
+        if (lm_head) TRY(tile_one(s, lm_head, &lm_head_t, cfg.vocab, Hh2));
+        HIPCHK(hipStreamSynchronize(s));
+    }
     HIPCHK(hipGetLastError());
     finalized = true;
+    return PG_OK;
+}
+int pg_engine::tile_one(hipStream_t s, const void* src, void** dst, int N, int K) {
+    if ((N & 15) || (K % 128)) { *dst = nullptr; return PG_OK; }
+    if (!*dst) TRY(dalloc(dst, (size_t)N * K * 2));
+    launch_tile_weights(s, (const bf16*)src, (bf16*)*dst, N, K);
     return PG_OK;
 }
 
 // =============================================================================== LLM
 // C = a . W^T into fp32 split-K slabs ``part`` [S_last][M][N].
 template <typename T>
-void pg_engine::gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, int K, bool allow_skinny) {
+void pg_engine::gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, int K, bool allow_skinny, const void* Wt) {
     slab_last = (long)M * N;
     if constexpr (std::is_same<T, bf16>::value) {
         if (allow_skinny && M <= 512 && K % 128 == 0) {
             const int S = skinny_pick_splits(N, K, M);
             if ((long)S * M * N <= part_elems) {
-                launch_gemm_skinny(s, a, W, part, M, N, K, S);
+                launch_gemm_skinny(s, a, W, part, M, N, K, S, (const bf16*)Wt);
                 S_last = S;
                 return;
             }
@@ -622,7 +657,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
     for (int li = 0; li < cfg.n_layers; ++li) {
         const Layer& ly = layers[li];
         launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);
-        gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk);
+        gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk, ly.wqkv_t);
         const bool timed = time_attn && mode == 0 && attn_ev_used + 2 <= attn_ev.size();
         if (mode == 0 && fuse_rope) {
             if (timed) (void)hipEventRecord(attn_ev[attn_ev_used], s);
@@ -646,23 +681,23 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
         if (timed) {
             (void)hipEventRecord(attn_ev[attn_ev_used + 1], s);
             double keys = shared_len;       // the shared uncond prompt is read from HBM once per launch
-            for (int r = 0; r < R; ++r) keys += (double)(h_len[r] + n_dec_host + 1) - ((shared_len > 0 && (r & 1)) ? shared_len : 0);
+            for (int r = 0; r < R; ++r) keys += (double)(h_len[h_len_off + r] + n_dec_host + 1) - ((shared_len > 0 && (r & 1)) ? shared_len : 0);
             attn_ev_bytes.push_back(keys * cfg.n_heads * 128 * 2 * (double)esz);
             attn_ev_used += 2;
         }
-        gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk);
+        gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk, ly.wo_t);
         launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);
         bool fused = false;
         if constexpr (std::is_same<T, bf16>::value) {
             // decode: SwiGLU gate fused into the gate|up GEMM epilogue (S = 1, no slab, no extra kernel)
             if (sk && M <= 512 && Hh % 128 == 0 && skinny_pick_splits(2 * I, Hh, M) == 1)
-                fused = launch_gemm_skinny_swiglu(s, (const bf16*)xn, (const bf16*)ly.wgu, (bf16*)hbuf, M, 2 * I, Hh);
+                fused = launch_gemm_skinny_swiglu(s, (const bf16*)xn, (const bf16*)ly.wgu, (bf16*)hbuf, M, 2 * I, Hh, (const bf16*)ly.wgu_t);
         }
         if (!fused) {
-            gemm_llm<T>(s, (const T*)xn, (const T*)ly.wgu, M, 2 * I, Hh, sk);
+            gemm_llm<T>(s, (const T*)xn, (const T*)ly.wgu, M, 2 * I, Hh, sk, ly.wgu_t);
             launch_silu_mul<T>(s, part, S_last, slab_last, (T*)hbuf, M, I);
         }
-        gemm_llm<T>(s, (const T*)hbuf, (const T*)ly.wd, M, Hh, I, sk);
+        gemm_llm<T>(s, (const T*)hbuf, (const T*)ly.wd, M, Hh, I, sk, ly.wd_t);
         S_pend = S_last; slab_pend = slab_last;
     }
     launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps);
@@ -720,6 +755,7 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     HIPCHK(hipMemcpyAsync(d_tok_j, s_j, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_tok_src, s_src, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(d_ndec, 0, 64, s));
+    HIPCHK(hipMemsetAsync(d_ndec2, 0, 64, s));
     // the pinned staging buffer is reused by the next call: wait for the copies
     HIPCHK(hipStreamSynchronize(s));
     if (ids_dev) launch_embed_gather(s, embed, ids_dev, d_tok_src, x, ntok, H(), cfg.vocab);
@@ -744,9 +780,9 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
 template <typename T>
 void pg_engine::head_logits(hipStream_t s, const T* in, int M) {
     const int Hh = H(), G = cfg.gen_head_dim, V = cfg.img_vocab;
-    gemm_llm<T>(s, in, (const T*)gh_w1, M, G, Hh, true);
+    gemm_llm<T>(s, in, (const T*)gh_w1, M, G, Hh, true, gh_w1_t);
     launch_bias_act<T>(s, part, S_last, slab_last, gh_b1, (T*)gh_mid, M, G, 1);
-    gemm_llm<T>(s, (const T*)gh_mid, (const T*)gh_w2, M, V, G, true);
+    gemm_llm<T>(s, (const T*)gh_mid, (const T*)gh_w2, M, V, G, true, gh_w2_t);
 }
 
 void pg_engine::forward_decode(hipStream_t s) {
@@ -761,56 +797,99 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     if (n_dec_host != 0) FAIL(PG_ERR_STATE, "decode loop needs a fresh prefill");
     if (T < 1 || T - 1 > cfg.max_new) FAIL(PG_ERR_CAPACITY, "T=%d exceeds max_new=%d", T, cfg.max_new);
     HIPCHK(hipSetDevice(dev));
-    const int B = R / 2;
+    const int Rtot = R, B = R / 2;
+    // Lanes: at large batch the rows are split into two independent chains on two streams so one
+    // half's latency-bound GEMM / norm kernels overlap the other half's bandwidth-bound attention.
+    // CFG pairs never straddle lanes; results are lane-independent (global image index in the RNG).
+    // Measured on MI355X at B=64: two lanes are 6 % SLOWER (kernels of both streams each fill the chip, the
+    // weights are read twice) -> one lane unless asked for (pg_set_option "lanes").
+    int nl = lanes_opt > 0 ? lanes_opt : 1;
+    if (Rtot % 4 || (long)decode_part_elems <= 0) nl = 1;
+    const bool graph = use_graph && !time_attn && T > 2;
+    struct LaneDef { int r0, nrows; float* part; int32_t* ndec; };
+    LaneDef ld[2];
+    ld[0] = {0, nl == 2 ? Rtot / 2 : Rtot, part, d_ndec};
+    ld[1] = {Rtot / 2, Rtot / 2, part2, d_ndec2};
+    // saved whole-batch views (a lane = pointer rebasing of the row-indexed buffers)
+    float* const x0 = x; void* const xn0 = xn; void* const q0 = qbuf; void* const o0 = obuf; void* const hb0 = hbuf;
+    void* const hf0 = hfin; void* const gm0 = gh_mid; float* const p0 = part; int32_t* const len0 = d_len;
+    int32_t* const po0 = d_pos_off; int32_t* const nd0 = d_ndec; float* const pv0 = cfg_pv; int* const pi0 = cfg_pi;
+    const int Hh = H(), HDm = HD(), G = cfg.gen_head_dim, I = cfg.inter;
+    auto enter = [&](const LaneDef& L) {
+        const size_t r = (size_t)L.r0;
+        x = x0 + r * Hh; xn = (char*)xn0 + r * Hh * esz; qbuf = (char*)q0 + r * HDm * esz; obuf = (char*)o0 + r * HDm * esz;
+        hbuf = (char*)hb0 + r * I * esz; hfin = (char*)hf0 + r * Hh * esz; gh_mid = (char*)gm0 + r * G * esz;
+        part = L.part; d_len = len0 + r; d_pos_off = po0 + r; d_ndec = L.ndec; cfg_pv = pv0 + r * 8; cfg_pi = pi0 + r * 8;
+        kv_row_off = r * cfg.n_heads * (size_t)slots * 128 * esz; shared_row = 1 - L.r0; h_len_off = L.r0; R = L.nrows;
+    };
+    auto leave = [&]() {
+        x = x0; xn = xn0; qbuf = q0; obuf = o0; hbuf = hb0; hfin = hf0; gh_mid = gm0; part = p0; d_len = len0; d_pos_off = po0;
+        d_ndec = nd0; cfg_pv = pv0; cfg_pi = pi0; kv_row_off = 0; shared_row = 1; h_len_off = 0; R = Rtot;
+    };
     SampleArgs sa{};
     sa.bias = gh_b2; sa.V = cfg.img_vocab; sa.cfg_weight = cfgw; sa.temperature = temp; sa.seed = seed;
     sa.force_tok = force_tok; sa.force_mask = force_mask; sa.T = T; sa.out_tok = out_tok; sa.logits_out = logits_out;
-    sa.embed_table = gen_table; sa.x = x; sa.H = H(); sa.n_dec = d_ndec;
-    auto sample = [&](hipStream_t st) {
+    sa.embed_table = gen_table; sa.H = Hh; sa.B_total = B;
+    auto sample = [&](hipStream_t st, const LaneDef& L) {
         if (bf) head_logits<bf16>(st, (const bf16*)hfin, R); else head_logits<float>(st, (const float*)hfin, R);
-        sa.logits_partial = part; sa.S = S_last; sa.slab = slab_last;
-        launch_cfg_sample(st, sa, B, cfg_pv, cfg_pi);
+        sa.logits_partial = part; sa.S = S_last; sa.slab = slab_last; sa.x = x; sa.n_dec = d_ndec; sa.b_off = L.r0 / 2;
+        launch_cfg_sample(st, sa, R / 2, cfg_pv, cfg_pi);
     };
     if (time_attn) {
-        const size_t need = (size_t)2 * cfg.n_layers * T;
+        const size_t need = (size_t)2 * cfg.n_layers * T * nl;
         while (attn_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); attn_ev.push_back(e); }
         attn_ev_used = 0; attn_ev_bytes.clear();
     }
-    const bool graph = use_graph && !time_attn && T > 2;
     hipStream_t ws = s;
-    if (graph) {      // graphs cannot be captured on the legacy default stream: hop to our own
+    if (graph || nl == 2) {      // graphs cannot be captured on the legacy default stream: hop to our own
         HIPCHK(hipEventRecord(ev_in, s));
         HIPCHK(hipStreamWaitEvent(istream, ev_in, 0));
         ws = istream;
     }
+    // one loop iteration for every lane: sample token i from hfin (step index = n_dec), then
+    // (with_forward) run the stack on its embedding (appends KV slot len+n_dec) and advance n_dec.
+    // In time_attn mode the lanes run back to back on one stream so the per-launch events are clean.
+    const bool two_streams = nl == 2 && !time_attn;
+    auto iteration = [&](bool with_forward) -> int {
+        if (two_streams) { HIPCHK(hipEventRecord(ev_fork, ws)); HIPCHK(hipStreamWaitEvent(istream2, ev_fork, 0)); }
+        for (int li = 0; li < nl; ++li) {
+            hipStream_t st = (two_streams && li == 1) ? istream2 : ws;
+            enter(ld[li]);
+            sample(st, ld[li]);
+            if (with_forward) forward_decode(st);
+            leave();
+        }
+        if (two_streams) { HIPCHK(hipEventRecord(ev_join, istream2)); HIPCHK(hipStreamWaitEvent(ws, ev_join, 0)); }
+        return PG_OK;
+    };
     HIPCHK(hipEventRecord(ev_t0, ws));
-    // iteration i: sample token i from hfin (step index = n_dec), then run the stack on its
-    // embedding (appends KV slot len+n_dec) and advance n_dec.  The last iteration only samples.
-    sample(ws);
-    if (T > 1) { forward_decode(ws); n_dec_host++; }
+    TRY(iteration(T > 1));
+    if (T > 1) n_dec_host++;
     int i = 1;
     if (graph) {
-        std::vector<int64_t> key = {R, T, (int64_t)bf, (int64_t)__builtin_bit_cast(int32_t, cfgw),
+        std::vector<int64_t> key = {Rtot, T, (int64_t)bf, (int64_t)__builtin_bit_cast(int32_t, cfgw),
                                     (int64_t)__builtin_bit_cast(int32_t, temp), (int64_t)seed, (int64_t)force_tok,
-                                    (int64_t)force_mask, (int64_t)out_tok, (int64_t)logits_out, (int64_t)shared_len, (int64_t)fuse_rope};
+                                    (int64_t)force_mask, (int64_t)out_tok, (int64_t)logits_out, (int64_t)shared_len, (int64_t)fuse_rope,
+                                    (int64_t)nl};
         if (!gexec || key != gkey) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal));
-            sample(ws);
-            forward_decode(ws);
-            HIPCHK(hipStreamEndCapture(ws, &g));
+            const int rc = iteration(true);
+            hipError_t ce = hipStreamEndCapture(ws, &g);
+            if (rc != PG_OK) return rc;
+            HIPCHK(ce);
             HIPCHK(hipGraphInstantiate(&gexec, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
             gkey = key;
         }
         for (; i < T - 1; ++i) { HIPCHK(hipGraphLaunch(gexec, ws)); n_dec_host++; }
     } else {
-        for (; i < T - 1; ++i) { sample(ws); forward_decode(ws); n_dec_host++; }
+        for (; i < T - 1; ++i) { TRY(iteration(true)); n_dec_host++; }
     }
-    if (T > 1) sample(ws);
+    if (T > 1) TRY(iteration(false));
     HIPCHK(hipEventRecord(ev_t1, ws));
-    if (graph) {
+    if (ws != s) {
         HIPCHK(hipEventRecord(ev_out, ws));
         HIPCHK(hipStreamWaitEvent(s, ev_out, 0));
     }
@@ -869,7 +948,7 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
     std::vector<int32_t> flags(1024);
     int checked = 0, done_len = -1;
     for (int step_i = 0; step_i < max_new; ++step_i) {
-        if (bf) gemm_llm<bf16>(s, (const bf16*)hfin, (const bf16*)lm_head, B, cfg.vocab, H(), true);
+        if (bf) gemm_llm<bf16>(s, (const bf16*)hfin, (const bf16*)lm_head, B, cfg.vocab, H(), true, lm_head_t);
         else gemm_llm<float>(s, (const float*)hfin, (const float*)lm_head, B, cfg.vocab, H(), true);
         ta.logits_partial = part; ta.S = S_last; ta.slab = slab_last;
         launch_text_argmax(s, ta, B);
@@ -1206,6 +1285,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
     if (!strcmp(key, "share_uncond")) { h->share_uncond = value != 0; return PG_OK; }
     if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
+    if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     h->err = std::string("unknown option ") + key;

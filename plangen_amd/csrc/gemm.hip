@@ -501,7 +501,7 @@ void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* o
 // rows in flight (the HBM requests of chunk c+D are issued while chunk c computes), the chunk
 // loop is fully unrolled (NCK = chunks per block, compile time) so the ring is statically
 // indexed.  XDB: x tile double-buffered (2 blocks/CU at MT=8) or single-buffered (4 blocks/CU).
-template <int MT, int NCK, int D, bool XDB, int EPI, int NW>
+template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
                                                                float* __restrict__ out, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -511,7 +511,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
     const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
     const int n = blockIdx.x * BN + w * 16 + lr;
     const int kbeg = split * NCK * SK_BK;
-    const bf16* wp = W + (long)(n < N ? n : N - 1) * K + kbeg + g * 8;
+    // Row-major W: lane (lr, g) reads W[n][k + i*32 + g*8 ..+8].  TILED W (decode copy, built at load
+    // time): [n-tile][k-chunk][i][lane][8] -- every wave load instruction is one contiguous 1 KiB and
+    // an n-tile's whole K stream is contiguous in HBM (DRAM-page friendly).
+    const int ntile = blockIdx.x * NW + w, ntiles = (N + 15) / 16;
+    const bf16* wp = TILED ? W + ((long)(ntile < ntiles ? ntile : ntiles - 1) * (K / SK_BK) + split * NCK) * 2048 + l * 8
+                           : W + (long)(n < N ? n : N - 1) * K + kbeg + g * 8;
+    constexpr int WCH = TILED ? 2048 : SK_BK, WI = TILED ? 512 : 32;       // element strides per chunk / per k-step
     const bf16* xp = x + kbeg;
 
     u32x4 xs[XV];
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
 #pragma unroll
     for (int c = 0; c < D && c < NCK; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wr[c][i] = *(const bf16x8*)(wp + c * SK_BK + i * 32);
+        for (int i = 0; i < 4; ++i) wr[c][i] = *(const bf16x8*)(wp + c * WCH + i * WI);
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
         skinny_mfma_chunk<MT>(xt, lr, g, wr[c % D], acc);
         if (c + D < NCK) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wr[c % D][i] = *(const bf16x8*)(wp + (c + D) * SK_BK + i * 32);
+            for (int i = 0; i < 4; ++i) wr[c % D][i] = *(const bf16x8*)(wp + (c + D) * WCH + i * WI);
         }
         if (c + 1 < NCK) {
             if (!XDB) __syncthreads();
@@ -560,11 +566,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
     if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid);
     else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * BN, w, g, lr, tid);
 }
-template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4>
+template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false>
 static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
     constexpr int XL = (XDB ? 2 : 1) * MT * 16 * SK_ROWB, TL = MT * 16 * (NW * 16 + 4) * 4;
     constexpr int LDS = XL > TL ? XL : TL;
-    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW>;
+    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
     dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
@@ -588,19 +594,50 @@ static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out,
 
 
 // ---- production dispatch: v3 (W register ring depth 2, double-buffered x tile) ----
-template <int MT, int EPI, int NW = 4>
+template <int MT, int EPI, int NW = 4, bool TILED = false>
 static bool sk3_prod_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck) {
     switch (nck) {
-        case 1: launch_sk3<MT, 1, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
-        case 2: launch_sk3<MT, 2, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
-        case 4: launch_sk3<MT, 4, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
-        case 8: launch_sk3<MT, 8, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
-        case 11: launch_sk3<MT, 11, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
-        case 16: launch_sk3<MT, 16, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
-        case 22: launch_sk3<MT, 22, 2, true, EPI, NW>(s, x, W, out, M, N, K, S); return true;
+        case 1: launch_sk3<MT, 1, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 2: launch_sk3<MT, 2, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 4: launch_sk3<MT, 4, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 8: launch_sk3<MT, 8, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 11: launch_sk3<MT, 11, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 16: launch_sk3<MT, 16, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 22: launch_sk3<MT, 22, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
         default: return false;
     }
 }
+// Build the decode ("tiled") copy of a row-major bf16 weight [N][K]: [n-tile 16][k-chunk 128][k-step i][lane][8].
+__global__ void tile_weights_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int N, int K) {
+    const long nvec = (long)N * K / 8;
+    const int nchunks = K / SK_BK;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(v & 63), i = (int)((v >> 6) & 3);
+        const long t = v >> 8;                                  // tile index = ntile * nchunks + chunk
+        const int chunk = (int)(t % nchunks); const long ntile = t / nchunks;
+        const long n = ntile * 16 + (lane & 15);
+        const int k = chunk * SK_BK + i * 32 + (lane >> 4) * 8;
+        *(u32x4*)(dst + v * 8) = *(const u32x4*)(src + n * K + k);
+    }
+}
+void launch_tile_weights(hipStream_t s, const bf16* src, bf16* dst, int N, int K) {
+    const long nvec = (long)N * K / 8;
+    const int blocks = (int)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 : 8192);
+    hipLaunchKernelGGL(tile_weights_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, K);
+}
+
+template <int EPI, bool TILED>
+static bool sk3_prod_tiled(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+    const int nck = K / SK_BK / S;
+    if (nck * S * SK_BK != K || (N & 15)) return false;
+    const int mrows = M < 128 ? M : 128;
+    if (mrows <= 16) return sk3_prod_nck<1, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck);
+    if (mrows <= 32) return sk3_prod_nck<2, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck);
+    // tiled weights: 64-row M blocks for every shape (measured best at M = 128: the second reader of a
+    // W tile hits L2, LDS per block halves -> more blocks per CU)
+    return sk3_prod_nck<4, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck);
+}
+
 template <int EPI>
 static bool sk3_prod(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
     const int nck = K / SK_BK / S;
@@ -620,7 +657,7 @@ void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* o
 // variant table for the microbenchmark (tools/skinny_sweep.py): returns BK (0 = unsupported)
 int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
     switch (variant) {
-        case 0: launch_gemm_skinny(s, x, W, out, M, N, K, S); return 128;                  // production (v3, falls back to v1)
+        case 0: launch_gemm_skinny(s, x, W, out, M, N, K, S, nullptr); return 128;         // production, row-major W (v3, falls back to v1)
         case 1: launch_gemm_skinny_v1(s, x, W, out, M, N, K, S); return 128;               // v1: 1-deep prefetch
         case 20: return sk3_dispatch<2, true>(s, x, W, out, M, N, K, S) ? 128 : 0;         // v3 ring 2, x double-buffered
         case 21: return sk3_dispatch<3, true>(s, x, W, out, M, N, K, S) ? 128 : 0;
@@ -634,19 +671,23 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
             launch_gemm<bf16>(s, a, W, K, K / S, e, M, N, K / S, S);
             return 64;
         }
+        case 50: return sk3_prod_nck<8, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W layout
+        case 51: return sk3_prod_nck<4, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W, 64-row M blocks
         case 26: return sk3_prod_nck<8, 0, 3>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;  // 48-column blocks (3 waves)
         case 27: return sk3_prod_nck<8, 0, 2>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;  // 32-column blocks (2 waves)
         default: return 0;
     }
 }
 
-void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, const bf16* Wt) {
     if (M <= 0) return;
+    if (Wt && sk3_prod_tiled<0, true>(s, x, Wt, out, M, N, K, S)) return;
     if (!sk3_prod<0>(s, x, W, out, M, N, K, S)) launch_gemm_skinny_v1(s, x, W, out, M, N, K, S);
 }
 // gate|up GEMM with the SwiGLU gate fused (S = 1): h bf16 [M, N/2].  Returns false when the
 // shape has no fused instantiation (caller falls back to slabs + silu_mul kernel).
-bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K) {
+bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K, const bf16* Wt) {
     if (M <= 0) return true;
+    if (Wt && sk3_prod_tiled<1, true>(s, x, Wt, (float*)h, M, N, K, 1)) return true;
     return sk3_prod<1>(s, x, W, (float*)h, M, N, K, 1);
 }

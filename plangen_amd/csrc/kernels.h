@@ -42,8 +42,10 @@ void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strid
 // Returns S.  N % 16 == 0, K % 128 == 0.
 int skinny_pick_splits(int N, int K);
 int skinny_pick_splits(int N, int K, int M);
-bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K);
-void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
+bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K, const bf16* Wt = nullptr);
+// Wt: optional tiled decode copy of W (launch_tile_weights); preferred when present
+void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, const bf16* Wt = nullptr);
+void launch_tile_weights(hipStream_t s, const bf16* src, bf16* dst, int N, int K);
 int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
 
 // ---------------------------------------------------------------- LLM elementwise / attention
@@ -113,6 +115,7 @@ struct SampleArgs {
     const float* embed_table;                                     // [V, H] fp32 (gen_embed->gen_aligner)
     float* x; int H;                                              // residual stream rows [2B, H]
     const int32_t* n_dec;
+    int b_off, B_total;                                           // this launch covers images [b_off, b_off + gridDim) of B_total
 };
 // scratch: >= 16*B floats and ints
 void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B, float* scratch_v, int* scratch_i);

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const float* __r
     };
     int kstart = 0;
     if (st.shared_len > 0 && (row & 1)) {       // uncond row: prompt K/V live once, in shared_row's region
-        const long sbase = ((long)st.shared_row * nh + head) * slots * 128 + lk * EPV;
+        const long sbase = ((long)st.shared_row * nh + head) * (long)slots * 128 + lk * EPV;   // shared_row is relative to this launch's row 0 (may be negative)
         kstart = st.shared_len < nprev ? st.shared_len : nprev;
         run(kc + sbase, vc + sbase, 0, kstart, std::false_type{});
     }
@@ -497,7 +497,7 @@ __device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int o
 __global__ __launch_bounds__(256) void cfg_scan_kernel(SampleArgs a, float* __restrict__ pv, int* __restrict__ pi) {
     __shared__ float sv[4]; __shared__ int si[4];
     const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
-    const int B = gridDim.y;
+    const int bg = b + a.b_off, B = a.B_total;            // global image index (lane-independent results)
     const int per = (a.V + CFG_CHUNKS - 1) / CFG_CHUNKS, v0 = ch * per, v1 = min(a.V, v0 + per);
     const long rc = (long)(2 * b) * a.V, ru = (long)(2 * b + 1) * a.V;
     float best = -INFINITY; int bi = 0x7fffffff;
@@ -509,9 +509,9 @@ __global__ __launch_bounds__(256) void cfg_scan_kernel(SampleArgs a, float* __re
             u += a.logits_partial[(long)s * a.slab + ru + v];
         }
         float mixed = u + a.cfg_weight * (c - u);
-        if (a.logits_out) a.logits_out[((long)step * B + b) * a.V + v] = mixed;
+        if (a.logits_out) a.logits_out[((long)step * B + bg) * a.V + v] = mixed;
         if (a.temperature > 0.f) {
-            const float uu = rng_uniform(a.seed, (uint64_t)b * 1000003ull + step, v);
+            const float uu = rng_uniform(a.seed, (uint64_t)bg * 1000003ull + step, v);
             mixed = mixed * invT - __logf(-__logf(uu));
         }
         if (mixed > best) { best = mixed; bi = v; }
@@ -537,12 +537,13 @@ __global__ __launch_bounds__(256) void cfg_pick_kernel(SampleArgs a, const float
         for (int k = 1; k < CFG_CHUNKS; ++k) argmax_combine(v, i, pv[b * CFG_CHUNKS + k], pi[b * CFG_CHUNKS + k]);
         i = i < 0 ? 0 : (i >= a.V ? a.V - 1 : i);
         int emit = i, feed = i;
+        const long bg = b + a.b_off;
         if (step < a.T && a.force_tok) {
-            const int f = a.force_tok[(long)b * a.T + step];
-            if (a.force_mask) { if (a.force_mask[(long)b * a.T + step] == 0) { emit = f; feed = f; } }
+            const int f = a.force_tok[bg * a.T + step];
+            if (a.force_mask) { if (a.force_mask[bg * a.T + step] == 0) { emit = f; feed = f; } }
             else feed = f;
         }
-        if (step < a.T) a.out_tok[(long)b * a.T + step] = emit;
+        if (step < a.T) a.out_tok[bg * a.T + step] = emit;
         feed = feed < 0 ? 0 : (feed >= a.V ? a.V - 1 : feed);
         s_tok = feed;
     }
