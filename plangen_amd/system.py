@@ -159,6 +159,50 @@ class System:
         return dec, toks
 
     @torch.no_grad()
+    def uni_generate(self, batch: dict, pred_layout: bool = False, is_mmu: bool = False, pred_image: bool = True,
+                     layout_to_prompt=None, max_new_tokens: int = 512, min_new_tokens: int = 0) -> dict:
+        """System.uni_generate (plangen_base.py:327-458) without the visualisation tail.
+
+        task_type 'uni'        : pred_layout=False -> t2i on batch['uni_inputs_ids'/'uni_attention_mask'].
+        task_type 'uni_2stage' : pred_layout=True  -> stage 1 greedy layout tokens from
+            batch['uni_stage1_inputs_ids'/'uni_stage1_attention_mask'] (x2t, :371-377), then
+            ``layout_to_prompt(sample_index, new_token_ids) -> list[int]`` rebuilds the stage-2 prompt ids
+            (the reference does this through the tokenizer on the host: decode_plan_text_batch +
+            wrap_uni_prompt, :296-306,:380-390), then t2i.
+        task_type 'mmu'        : is_mmu=True, pred_image=False -> prepare_inputs_embeds(**batch[
+            'prepare_inputs_infer']) (:365-366) + greedy text decode.
+        Negative prompt ids: batch['neg_inputs_ids'] (one shared list, or one per sample).
+        Returns dict(pr_tokens=..., pr_image=..., pr_layout_ids=..., pr_text_ids=...)."""
+        out = {}
+        dev = self.device
+        if is_mmu:
+            emb = self.vl_gpt.prepare_inputs_embeds(**batch["prepare_inputs_infer"])
+            out["pr_text_ids"] = self.x2t(emb, batch["prepare_inputs_infer"]["attention_mask"].to(dev),
+                                          max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens)
+            if not pred_image:
+                return out
+        if pred_layout:
+            ids1 = batch["uni_stage1_inputs_ids"].to(dev)
+            emb1 = self.vl_gpt.language_model.get_input_embeddings()(ids1)
+            layout = self.x2t(emb1, batch["uni_stage1_attention_mask"].to(dev), max_new_tokens=max_new_tokens,
+                              min_new_tokens=min_new_tokens)
+            out["pr_layout_ids"] = layout
+            if layout_to_prompt is None:
+                raise PlanGenError("uni_2stage needs layout_to_prompt (tokenizer round trip of the predicted layout)")
+            rows = layout.cpu().tolist()
+            cond = [list(layout_to_prompt(i, r)) for i, r in enumerate(rows)]
+        else:
+            ids, mask = batch["uni_inputs_ids"], batch["uni_attention_mask"]
+            L = ids.shape[1]
+            m = mask[:, :L]
+            cond = [ids[i][m[i].bool()].tolist() for i in range(ids.shape[0])]
+        cfg_ids, cfg_mask = self.t2i_infer_collate_batch(cond, batch["neg_inputs_ids"])
+        dec, toks = self.t2i(cfg_ids, cfg_mask, gt_image=batch.get("image"), edit_region=batch.get("edit_region"))
+        out["pr_tokens"] = toks
+        out["pr_image"] = dec.float()
+        return out
+
+    @torch.no_grad()
     def x2t(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
             max_new_tokens: int = 512, min_new_tokens: int = 0) -> torch.Tensor:
         """System.x2t (:513-523): greedy text / layout-token decode."""

@@ -302,3 +302,30 @@ def test_two_decode_lanes_equal_one_lane(tiny_cfg, tiny_weights, ocfg):
         samp.append(e.decode_image_tokens(T=10, cfg_weight=5.0, temperature=1.0, seed=3).cpu())
     e.set_option("lanes", -1)
     assert torch.equal(samp[0], samp[1])
+
+
+def test_uni_2stage_layout_then_image(tiny_cfg, tiny_weights, ocfg):
+    """task_type='uni_2stage' (plangen_base.py:1117-1118): greedy layout tokens, host hand-off, then
+    the CFG image loop; both stages bit-exact vs the oracle in fp32."""
+    from plangen_amd.system import System, pad_input_ids
+    e = get_engine(tiny_cfg, tiny_weights, "f32")
+    sysm = System(tiny_cfg, e)
+    sysm.args.temperature = 0.0
+    g = torch.Generator().manual_seed(51)
+    stage1 = [torch.randint(8, tiny_cfg.vocab, (n,), generator=g).tolist() for n in (7, 4)]
+    neg = torch.randint(8, tiny_cfg.vocab, (5,), generator=g).tolist()
+    ids1, mask1 = pad_input_ids(stage1, tiny_cfg.pad_id)
+
+    def layout_to_prompt(i, new_ids):            # stand-in for decode_plan_text_batch + wrap_uni_prompt
+        keep = [t for t in new_ids if t != tiny_cfg.eos_id][:6]
+        return stage1[i] + keep + [9]
+
+    batch = dict(uni_stage1_inputs_ids=ids1, uni_stage1_attention_mask=mask1, neg_inputs_ids=neg)
+    out = sysm.uni_generate(batch, pred_layout=True, layout_to_prompt=layout_to_prompt, max_new_tokens=8)
+    ref_layout = R.generate_text_greedy(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids1), mask1, 8, tiny_cfg.eos_id)
+    assert np.array_equal(out["pr_layout_ids"].cpu().numpy(), ref_layout.numpy())
+    cond = [layout_to_prompt(i, r) for i, r in enumerate(ref_layout.tolist())]
+    cids, cmask = R.t2i_infer_collate_batch(cond, neg, tiny_cfg.pad_id, tiny_cfg.img_tokens)
+    ref_tok, ref_img = R.t2i(tiny_weights, ocfg, cids, cmask, 5.0)
+    assert np.array_equal(out["pr_tokens"].cpu().numpy(), ref_tok.numpy())
+    assert ((out["pr_image"].cpu() - ref_img) ** 2).mean().item() <= PIXEL_MSE
