@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -139,7 +140,8 @@ struct pg_engine {
     int h_len_off = 0; int lanes_opt = -1;   // -1 auto, 1, 2
     float* part2 = nullptr; hipStream_t istream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int32_t* d_ndec2 = nullptr;
-    SeqState seq() const { return SeqState{d_len, d_pos_off, d_ndec, d_tok_row, d_tok_j, shared_len, shared_row}; }
+    int32_t* d_row_order = nullptr; bool lpt_order = true; bool order_valid = false; int order_rows = 0;
+    SeqState seq() const { return SeqState{d_len, d_pos_off, d_ndec, d_tok_row, d_tok_j, shared_len, shared_row, (lpt_order && order_valid && kv_row_off == 0 && R == order_rows) ? d_row_order : nullptr}; }
 
     int create();
     void add_slot(const std::string& name, void* dst, SlotKind k, long n, int a = 0, int b = 0, int c = 0);
@@ -418,6 +420,7 @@ int pg_engine::create() {
     TRY(dalloc(&d_pos_off, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_last, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_row_off, (size_t)cfg.max_rows * 4));
+    TRY(dalloc(&d_row_order, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_unf, (size_t)cfg.max_rows * 4));
     TRY(dalloc(&d_anyunf, 1024 * 4));
     TRY(dalloc(&d_ndec, 64));
@@ -746,6 +749,16 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
         s_last[r] = ntok - 1;
     }
     R = R_; L = L_; Ntok = ntok; pos_mode = pmode; n_dec_host = 0;
+    {   // longest-first row order for the decode attention launch (private keys per row)
+        std::vector<int32_t> ord(R_);
+        for (int r = 0; r < R_; ++r) ord[r] = r;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+            const int ka = h_len[a] - ((shared_len > 0 && (a & 1)) ? shared_len : 0), kb = h_len[b] - ((shared_len > 0 && (b & 1)) ? shared_len : 0);
+            return ka > kb; });
+        HIPCHK(hipMemcpyAsync(d_row_order, ord.data(), (size_t)R_ * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        order_valid = true; order_rows = R_;
+    }
     HIPCHK(hipEventRecord(ev_p0, s));
     HIPCHK(hipMemcpyAsync(d_len, s_len, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_pos_off, s_off, (size_t)R * 4, hipMemcpyHostToDevice, s));
@@ -1286,6 +1299,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "share_uncond")) { h->share_uncond = value != 0; return PG_OK; }
     if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
     if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
+    if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     h->err = std::string("unknown option ") + key;

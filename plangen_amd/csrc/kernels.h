@@ -74,6 +74,7 @@ struct SeqState {              // device arrays describing the rows of the curre
     const int32_t* tok_j;      // [Ntok] prefill: slot of packed token t
     int shared_len;            // > 0: odd (uncond CFG) rows share one prompt; its K/V (slots [0, shared_len)) live in row shared_row only
     int shared_row;
+    const int32_t* row_order;  // decode attention: blockIdx.y -> row, longest rows first (may be null)
 };
 // qkv partial fp32 [S, M, 3*nh*128] -> RoPE(q), RoPE(k); q -> qbuf T [M, nh*128];
 // k,v -> caches [R][nh][slots][128].  mode 0: decode (token m = row m, slot = len+n_dec);

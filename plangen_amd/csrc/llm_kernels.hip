@@ -290,7 +290,9 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const float* __r
     __shared__ __attribute__((aligned(16))) float s_q[128];
     __shared__ float s_k[128], s_v[128];
     __shared__ float s_new;
-    const int row = blockIdx.x, head = blockIdx.y;
+    // blocks are dispatched in linear order (x fastest): heads of the LONGEST row first, so the
+    // ragged tail of the launch is made of short rows (longest-processing-time-first packing)
+    const int head = blockIdx.x, row = st.row_order ? st.row_order[blockIdx.y] : blockIdx.y;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int grp = l / LPK, lk = l % LPK;
     const int slot = st.len[row] + *st.n_dec;             // where the new key goes
@@ -415,7 +417,7 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
                               const float* cos_t, const float* sin_t, SeqState st, int M, int nh, int slots,
                               int max_pos, float scale) {
     if (M <= 0) return;
-    hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8>), dim3(M, nh), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
+    hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
                        st, nh, slots, max_pos, scale);
 }
 template void launch_attn_decode_fused<float>(hipStream_t, const float*, int, long, float*, float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
