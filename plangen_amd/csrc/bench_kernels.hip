@@ -43,3 +43,43 @@ extern "C" int pg_bench_skinny(int M, int N, int K, int variant, int S, int iter
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
     return rc;
 }
+
+// Pure streaming read (calibration for the HBM-bound kernels): every block reads a contiguous
+// slice with 16-byte loads, UN loads in flight per lane, result folded into one word per block.
+template <bool NT>
+__global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restrict__ p, long nvec_per_block, uint32_t* __restrict__ out) {
+    const u32x4* b = p + (long)blockIdx.x * nvec_per_block;
+    uint32_t acc = 0;
+    for (long i = threadIdx.x; i < nvec_per_block; i += 256 * 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long j = i + (long)u * 256;
+            const long jj = j < nvec_per_block ? j : nvec_per_block - 1;
+            v[u] = NT ? __builtin_nontemporal_load(b + jj) : b[jj];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x12345678u) out[blockIdx.x] = acc;
+}
+extern "C" int pg_bench_stream(long bytes, int blocks, int iters, int nt, float* us_out) {
+    const long total = 3 * bytes;                      // rotate through 3 regions (> Infinity Cache)
+    char* buf; if (hipMalloc((void**)&buf, total) != hipSuccess) return -2;
+    hipMemset(buf, 1, total);
+    uint32_t* out; hipMalloc((void**)&out, blocks * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipStream_t s; hipStreamCreate(&s);
+    const long nvpb = bytes / 16 / blocks;
+    for (int it = -3; it < iters; ++it) {
+        if (it == 0) hipEventRecord(e0, s);
+        const u32x4* p = (const u32x4*)(buf + (long)((it + 3) % 3) * bytes);
+        if (nt) hipLaunchKernelGGL(stream_read_kernel<true>, dim3(blocks), dim3(256), 0, s, p, nvpb, out);
+        else hipLaunchKernelGGL(stream_read_kernel<false>, dim3(blocks), dim3(256), 0, s, p, nvpb, out);
+    }
+    hipEventRecord(e1, s); hipStreamSynchronize(s);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    if (us_out) *us_out = ms * 1e3f / iters;
+    hipFree(buf); hipFree(out); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    return 0;
+}

@@ -5,6 +5,28 @@
 #include <type_traits>
 #include "kernels.h"
 
+
+// acc[v] += sum_s p[s*slab + offs[v]] with the loads of 4 slabs x NV values issued together
+// (hipcc does not unroll a runtime-S loop: a plain loop costs S dependent memory round trips).
+template <int NV>
+__device__ __forceinline__ void sum_slabs(const float* __restrict__ p, long slab, int S, const int (&offs)[NV], float (&acc)[NV]) {
+    for (int s0 = 0; s0 < S; s0 += 4) {
+        float t[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* q = p + (long)(s0 + u < S ? s0 + u : S - 1) * slab;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) t[u][v] = q[offs[v]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s0 + u < S) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += t[u][v];
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------- RMSNorm
 // One 256-thread block per row.  x += sum_s partial[s]; xn = w * (x * rsqrt(mean(x^2)+eps)).
 // LlamaRMSNorm: stats in fp32, normalised value cast to the input dtype (fp32 residual
@@ -27,7 +49,19 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
         v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (i < H) {
             v[j] = *(const f32x4*)(xr + i);
-            for (int s = 0; s < S; ++s) v[j] += *(const f32x4*)(partial + (long)s * slab + (long)m * H + i);
+            // slab loads in batches of 8 independent requests (a plain ``for s`` loop is not unrolled
+            // by hipcc for runtime S and degenerates into S dependent round trips)
+            const float* pp = partial + (long)m * H + i;
+            for (int s0 = 0; s0 < S; s0 += 8) {
+                f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = s0 + u < S ? s0 + u : S - 1;
+                    t[u] = *(const f32x4*)(pp + (long)s * slab);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (s0 + u < S) v[j] += t[u];
+            }
             if (S > 0) *(f32x4*)(xr + i) = v[j];
             ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
         }
@@ -148,11 +182,10 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float* __restrict__ 
     if (slot >= slots) return;                                     // capacity guard (host checks too)
     const int HD = nh * 128;
     const long base = (long)m * 3 * HD + head * 128 + j;
-    float q0 = 0, q1 = 0, k0 = 0, k1 = 0, v0 = 0, v1 = 0;
-    for (int s = 0; s < S; ++s) {
-        const float* p = qkv + (long)s * slab + base;
-        q0 += p[0]; q1 += p[64]; k0 += p[HD]; k1 += p[HD + 64]; v0 += p[2 * HD]; v1 += p[2 * HD + 64];
-    }
+    float a6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int o6[6] = {0, 64, HD, HD + 64, 2 * HD, 2 * HD + 64};
+    sum_slabs<6>(qkv + base, slab, S, o6, a6);
+    const float q0 = a6[0], q1 = a6[1], k0 = a6[2], k1 = a6[3], v0 = a6[4], v1 = a6[5];
     const float c = cos_t[(long)pos * 64 + j], sn = sin_t[(long)pos * 64 + j];
     T* qo = qbuf + (long)m * HD + head * 128 + j;
     ET<T>::st(qo, q0 * c - q1 * sn);
@@ -304,11 +337,10 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const float* __r
         int pos = st.pos_off[row] + slot;
         if (pos >= max_pos) pos = max_pos - 1;
         const long base = (long)row * 3 * HD + head * 128 + j;
-        float q0 = 0, q1 = 0, k0 = 0, k1 = 0, v0 = 0, v1 = 0;
-        for (int s = 0; s < S; ++s) {
-            const float* p = qkv + (long)s * slab + base;
-            q0 += p[0]; q1 += p[64]; k0 += p[HD]; k1 += p[HD + 64]; v0 += p[2 * HD]; v1 += p[2 * HD + 64];
-        }
+        float a6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int o6[6] = {0, 64, HD, HD + 64, 2 * HD, 2 * HD + 64};
+        sum_slabs<6>(qkv + base, slab, S, o6, a6);
+        const float q0 = a6[0], q1 = a6[1], k0 = a6[2], k1 = a6[3], v0 = a6[4], v1 = a6[5];
         const float c = cos_t[(long)pos * 64 + j], sn = sin_t[(long)pos * 64 + j];
         // the query is rounded to T exactly like the unfused path (qbuf was T), then pre-scaled
         s_q[j] = ET<T>::round(q0 * c - q1 * sn) * scale;
@@ -449,8 +481,10 @@ __global__ void silu_mul_kernel(const float* __restrict__ gu, int S, long slab, 
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= I) return;
     const long cg = (long)m * 2 * I + (n >> 3) * 16 + (n & 7);
-    float g = 0.f, u = 0.f;
-    for (int s = 0; s < S; ++s) { g += gu[(long)s * slab + cg]; u += gu[(long)s * slab + cg + 8]; }
+    float a2[2] = {0.f, 0.f};
+    const int o2[2] = {0, 8};
+    sum_slabs<2>(gu + cg, slab, S, o2, a2);
+    const float g = a2[0], u = a2[1];
     ET<T>::st(h + (long)m * I + n, (g / (1.f + expf(-g))) * u);
 }
 template <typename T>
@@ -466,8 +500,10 @@ __global__ void bias_act_kernel(const float* __restrict__ partial, int S, long s
                                 T* __restrict__ out, int N, int act) {
     const int m = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    float v = bias ? bias[n] : 0.f;
-    for (int s = 0; s < S; ++s) v += partial[(long)s * slab + (long)m * N + n];
+    float a1[1] = {bias ? bias[n] : 0.f};
+    const int o1[1] = {0};
+    sum_slabs<1>(partial + (long)m * N + n, slab, S, o1, a1);
+    float v = a1[0];
     if (act == 1) v = gelu_erf(v);
     ET<T>::st(out + (long)m * N + n, v);
 }
@@ -505,11 +541,11 @@ __global__ __launch_bounds__(256) void cfg_scan_kernel(SampleArgs a, float* __re
     float best = -INFINITY; int bi = 0x7fffffff;
     const float invT = a.temperature > 0.f ? 1.f / a.temperature : 1.f;
     for (int v = v0 + tid; v < v1; v += 256) {
-        float c = a.bias ? a.bias[v] : 0.f, u = c;
-        for (int s = 0; s < a.S; ++s) {
-            c += a.logits_partial[(long)s * a.slab + rc + v];
-            u += a.logits_partial[(long)s * a.slab + ru + v];
-        }
+        const float b0 = a.bias ? a.bias[v] : 0.f;
+        float cu[2] = {b0, b0};
+        const int ocu[2] = {0, a.V};                          // cond row, uncond row (adjacent rows)
+        sum_slabs<2>(a.logits_partial + rc + v, a.slab, a.S, ocu, cu);
+        const float c = cu[0], u = cu[1];
         float mixed = u + a.cfg_weight * (c - u);
         if (a.logits_out) a.logits_out[((long)step * B + bg) * a.V + v] = mixed;
         if (a.temperature > 0.f) {
@@ -570,8 +606,10 @@ __global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a) {
     const int b = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int v = tid; v < a.V; v += 256) {
-        float c = 0.f;
-        for (int s = 0; s < a.S; ++s) c += a.logits_partial[(long)s * a.slab + (long)b * a.V + v];
+        float c1[1] = {0.f};
+        const int oc1[1] = {0};
+        sum_slabs<1>(a.logits_partial + (long)b * a.V + v, a.slab, a.S, oc1, c1);
+        float c = c1[0];
         if (v == a.eos && step < a.min_new) c = -INFINITY;
         if (c > best) { best = c; bi = v; }
     }
