@@ -329,3 +329,25 @@ def test_uni_2stage_layout_then_image(tiny_cfg, tiny_weights, ocfg):
     ref_tok, ref_img = R.t2i(tiny_weights, ocfg, cids, cmask, 5.0)
     assert np.array_equal(out["pr_tokens"].cpu().numpy(), ref_tok.numpy())
     assert ((out["pr_image"].cpu() - ref_img) ** 2).mean().item() <= PIXEL_MSE
+
+
+def test_checkpoint_formats_roundtrip(tiny_cfg, tiny_weights, tmp_path):
+    """HF safetensors base + PlanGen '.pth' overlay with the 'vl_gpt.' prefix (base_system.py:153-189)."""
+    from safetensors.torch import save_file
+    from plangen_amd.engine import Engine
+    from plangen_amd.weights import load_checkpoint
+    keep = {k: v.contiguous() for k, v in tiny_weights.items()
+            if not k.startswith(("vision_model.", "aligner.", "gen_vision_model.encoder", "gen_vision_model.quant_conv"))}
+    save_file(keep, str(tmp_path / "model.safetensors"))
+    bias = tiny_weights["gen_head.vision_head.bias"] + 1.5
+    ck = tmp_path / "checkpoint-7"
+    ck.mkdir()
+    torch.save({"vl_gpt.gen_head.vision_head.bias": bias}, str(ck / "trainable_model_parameters.pth"))
+    e = Engine(tiny_cfg, dtype="f32", max_rows=4, max_prompt=16, max_images=1, with_lm_head=True)
+    info = load_checkpoint(e, str(tmp_path), overlay=str(ck))
+    assert info["skipped"] == []
+    g = load_golden("sample_image_tiny.npz")
+    h = torch.from_numpy(g["last_hidden"][0])
+    W2 = dict(tiny_weights); W2["gen_head.vision_head.bias"] = bias
+    assert (e.gen_head(h).cpu() - R.gen_head(W2, h)).abs().max() < 1e-4
+    e.close()

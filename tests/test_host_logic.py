@@ -94,3 +94,19 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_checkpoint_discovery_and_safetensors_iteration(tmp_path):
+    """HF safetensors directory + PlanGen 'latest' checkpoint discovery (no GPU)."""
+    from safetensors.torch import save_file
+    from plangen_amd.weights import iter_safetensors, latest_checkpoint
+    a = {"gen_embed.weight": torch.randn(4, 8), "language_model.model.norm.weight": torch.ones(6)}
+    b = {"gen_head.vision_head.bias": torch.zeros(5)}
+    save_file(a, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file(b, str(tmp_path / "model-00002-of-00002.safetensors"))
+    got = dict(iter_safetensors(str(tmp_path)))
+    assert set(got) == set(a) | set(b) and torch.equal(got["gen_embed.weight"], a["gen_embed.weight"])
+    for step in (10, 200, 30):
+        (tmp_path / f"checkpoint-{step}").mkdir()
+    assert latest_checkpoint(str(tmp_path)).endswith("checkpoint-200")
+    assert latest_checkpoint(str(tmp_path / "checkpoint-10")) is None
