@@ -343,7 +343,7 @@ def test_checkpoint_formats_roundtrip(tiny_cfg, tiny_weights, tmp_path):
     ck = tmp_path / "checkpoint-7"
     ck.mkdir()
     torch.save({"vl_gpt.gen_head.vision_head.bias": bias}, str(ck / "trainable_model_parameters.pth"))
-    e = Engine(tiny_cfg, dtype="f32", max_rows=4, max_prompt=16, max_images=1, with_lm_head=True)
+    e = Engine(tiny_cfg, dtype="f32", max_rows=8, max_prompt=16, max_images=1, with_lm_head=True)
     info = load_checkpoint(e, str(tmp_path), overlay=str(ck))
     assert info["skipped"] == []
     g = load_golden("sample_image_tiny.npz")
