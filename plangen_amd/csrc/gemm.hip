@@ -594,16 +594,16 @@ static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out,
 
 
 // ---- production dispatch: v3 (W register ring depth 2, double-buffered x tile) ----
-template <int MT, int EPI, int NW = 4, bool TILED = false>
+template <int MT, int EPI, int NW = 4, bool TILED = false, int D = 2>
 static bool sk3_prod_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck) {
     switch (nck) {
-        case 1: launch_sk3<MT, 1, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 2: launch_sk3<MT, 2, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 4: launch_sk3<MT, 4, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 8: launch_sk3<MT, 8, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 11: launch_sk3<MT, 11, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 16: launch_sk3<MT, 16, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 22: launch_sk3<MT, 22, 2, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 1: launch_sk3<MT, 1, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 2: launch_sk3<MT, 2, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 4: launch_sk3<MT, 4, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 8: launch_sk3<MT, 8, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 11: launch_sk3<MT, 11, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 16: launch_sk3<MT, 16, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 22: launch_sk3<MT, 22, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
         default: return false;
     }
 }
@@ -660,10 +660,7 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 0: launch_gemm_skinny(s, x, W, out, M, N, K, S, nullptr); return 128;         // production, row-major W (v3, falls back to v1)
         case 1: launch_gemm_skinny_v1(s, x, W, out, M, N, K, S); return 128;               // v1: 1-deep prefetch
         case 20: return sk3_dispatch<2, true>(s, x, W, out, M, N, K, S) ? 128 : 0;         // v3 ring 2, x double-buffered
-        case 21: return sk3_dispatch<3, true>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 23: return sk3_dispatch<2, false>(s, x, W, out, M, N, K, S) ? 128 : 0;        // x single-buffered
         case 24: return sk3_prod_nck<4, 0>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // 64-row M blocks (grid.z = M/64)
-        case 25: return sk3_prod_nck<2, 0>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // 32-row M blocks
         case 40: {   // MFMA tile kernel (128x128x64, glds) with split-K expressed through the batch strides
             if (K % (64 * S)) return 0;
             GemmA a; a.ptr = x; a.lda = K; a.strideA = K / S;
@@ -673,8 +670,6 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         }
         case 50: return sk3_prod_nck<8, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W layout
         case 51: return sk3_prod_nck<4, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W, 64-row M blocks
-        case 26: return sk3_prod_nck<8, 0, 3>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;  // 48-column blocks (3 waves)
-        case 27: return sk3_prod_nck<8, 0, 2>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;  // 32-column blocks (2 waves)
         default: return 0;
     }
 }
