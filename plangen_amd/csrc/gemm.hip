@@ -34,7 +34,8 @@ template <typename T>
 struct ConvLoader {
     const T* X; const T* zeros; int Hi, Wi, Cin, up, stride2, Ho, Wo, M;
     const T* img[4]; int yy[4], xx[4];
-    int dy, dx, ci0;
+    const T* cur[4];               // source pixel of the CURRENT tap for each staging slot (nullptr = halo -> zeros)
+    int ci0, cur_tap;
     __device__ __forceinline__ void decode(int m, int& b, int& y, int& x) const {
         x = m % Wo; int t = m / Wo; y = t % Ho; b = t / Ho;
     }
@@ -42,9 +43,7 @@ struct ConvLoader {
         if (m >= M) m = M - 1;
         int b, y, x; decode(m, b, y, x);
         img[i] = X + (long)b * Hi * Wi * Cin; yy[i] = y; xx[i] = x;
-    }
-    __device__ __forceinline__ void set_ktile(int k0) {
-        const int tap = k0 / Cin; ci0 = k0 - tap * Cin; dy = tap / 3; dx = tap - dy * 3;
+        cur_tap = -1;
     }
     __device__ __forceinline__ bool src_yx(int y, int x, int ddy, int ddx, int& sy, int& sx) const {
         if (stride2) { sy = 2 * y + ddy; sx = 2 * x + ddx; return sy < Hi && sx < Wi; }
@@ -52,11 +51,25 @@ struct ConvLoader {
         sy = oy >> up; sx = ox >> up;
         return oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
     }
+    // K tiles arrive in increasing k; the halo test and the 64-bit address are recomputed only when
+    // the tap changes (every Cin/64 tiles).  Cin is a power of two (64..512): shift / mask.
+    __device__ __forceinline__ void set_ktile(int k0) {
+        const int lc = 31 - __builtin_clz(Cin);
+        const int tap = k0 >> lc; ci0 = k0 & (Cin - 1);
+        if (tap != cur_tap) {
+            cur_tap = tap;
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int sy, sx;
+                cur[i] = src_yx(yy[i], xx[i], dy, dx, sy, sx) ? img[i] + ((long)sy * Wi + sx) * Cin : nullptr;
+            }
+        }
+    }
     // k = k-tile base + chunk offset (chunk of 8 elements inside one tap because Cin % 64 == 0)
     __device__ __forceinline__ const T* ptr(int i, int k) const {
-        int sy, sx; const int koff = k & 63;
-        if (!src_yx(yy[i], xx[i], dy, dx, sy, sx)) return zeros + koff;
-        return img[i] + ((long)sy * Wi + sx) * Cin + ci0 + koff;
+        const int koff = k & 63;
+        return cur[i] ? cur[i] + ci0 + koff : zeros + koff;
     }
     __device__ __forceinline__ float elem(int m, int k) const {
         if (m >= M) return 0.f;
