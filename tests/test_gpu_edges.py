@@ -1,5 +1,7 @@
 """GPU: edge cases of the path through the C ABI -- minimal and ragged batches, capacity limits,
 call-order errors, per-sample negative prompts (no sharing), temperature extremes."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,3 +121,20 @@ def test_temperature_limits(tiny_cfg, tiny_weights):
     e.prefill(ids, pad)
     hot = e.decode_image_tokens(T=6, cfg_weight=5.0, temperature=50.0, seed=5).cpu()
     assert (hot >= 0).all() and (hot < tiny_cfg.img_vocab).all()
+
+
+def test_cli_validation_writes_images(tmp_path):
+    """python train.py --cfg ... --opt test=True ... -> System.validation (tiny config, synthetic prompts)."""
+    import train
+    out = train.parse_args(["--cfg", "project/plangen/cfg/uni/h_text_ump+oimsam.py", "--opt", "test=True", "tiny=True",
+                            "resume=None", f"out_path='{tmp_path}'", "test_batch_size=2", "max_test_len=2", "max_prompt=64",
+                            "janus_path=None"])
+    import importlib
+    System = importlib.import_module(out.system_cls_path).System
+    m = System(out, None)
+    m.setup_data(None)
+    m.resume(None)
+    res = m.validation(0)
+    assert res["images"] == 4
+    files = os.listdir(res["out_dir"])
+    assert sum(f.endswith((".png", ".pt")) for f in files) == 4 and sum(f.endswith("_tokens.json") for f in files) == 2

@@ -110,3 +110,13 @@ def test_checkpoint_discovery_and_safetensors_iteration(tmp_path):
         (tmp_path / f"checkpoint-{step}").mkdir()
     assert latest_checkpoint(str(tmp_path)).endswith("checkpoint-200")
     assert latest_checkpoint(str(tmp_path / "checkpoint-10")) is None
+
+
+def test_cli_config_loader_matches_reference_shape():
+    """train.py --cfg <python cfg with _base_> --opt dotted=overrides (train.py:23-49)."""
+    import train
+    a = train.parse_args(["--cfg", os.path.join(ROOT, "project/plangen/cfg/uni/h_text_ump+oimsam.py"), "--opt", "test=True",
+                          "test_data.task_type='uni_2stage'", "cfg_weight=3.5", "resume=None"])
+    assert a.test is True and a.cfg_weight == 3.5 and a.resume is None
+    assert a.test_data["task_type"] == "uni_2stage" and a.test_data["data_name"] == "synthetic"
+    assert a.out_path.endswith("h_text_ump+oimsam") and a.system_cls_path == "project.plangen.plangen_base"
