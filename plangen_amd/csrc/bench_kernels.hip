@@ -83,3 +83,58 @@ extern "C" int pg_bench_stream(long bytes, int blocks, int iters, int nt, float*
     hipFree(buf); hipFree(out); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
     return 0;
 }
+
+// ------------------------------------------------------------------------------- big GEMM / conv
+// Times launch_gemm<bf16> (plain A, or the implicit-im2col 3x3 conv loader when Hi > 0) with the
+// 256x256 kernel on (mode 1/2) or off (mode 0), and returns the max |difference| between the two
+// kernels' fp32 outputs on uniform random operands (verify != 0).
+__global__ void maxdiff_kernel(const float* a, const float* b, long n, float* out) {
+    float m = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = fabsf(a[i] - b[i]);
+        m = fmaxf(m, d != d ? 1e30f : d);
+    }
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax((int*)out, __float_as_int(m));
+}
+extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int up, int mode, int iters, int verify,
+                             float* us_out, float* maxdiff_out) {
+    const bool conv = Hi > 0;
+    int B = 1;
+    long a_elems = (long)M * K;
+    if (conv) { const int Ho = Hi << up, Wo = Wi << up; B = M / (Ho * Wo); a_elems = (long)B * Hi * Wi * Cin; K = 9 * Cin; }
+    bf16 *A, *Wt, *zeros; float *o0, *o1, *md;
+    if (hipMalloc((void**)&A, a_elems * 2) != hipSuccess) return -2;
+    hipMalloc((void**)&Wt, (long)N * K * 2); hipMalloc((void**)&zeros, 4096); hipMemset(zeros, 0, 4096);
+    hipMalloc((void**)&o0, (long)M * N * 4); hipMalloc((void**)&md, 4); hipMemset(md, 0, 4);
+    o1 = nullptr;
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 11u);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, Wt, (long)N * K, 5u);
+    hipStream_t s; hipStreamCreate(&s);
+    GemmA ga; ga.ptr = A; ga.lda = K;
+    if (conv) { ga.kind = 1; ga.Hi = Hi; ga.Wi = Wi; ga.Cin = Cin; ga.up = up; ga.zeros = zeros; }
+    GemmEpi e; e.out = o0; e.out_f32 = 1; e.ldc = N;
+    const int saved = g_gemm256;
+    hipDeviceSynchronize();
+    if (verify) {
+        hipMalloc((void**)&o1, (long)M * N * 4);
+        g_gemm256 = 0; e.out = o1; launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
+        g_gemm256 = mode ? mode : 1; e.out = o0; hipMemsetAsync(o0, 0xff, (long)M * N * 4, s); launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
+        hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, s, o0, o1, (long)M * N, md);
+        hipStreamSynchronize(s);
+        hipMemcpy(maxdiff_out, md, 4, hipMemcpyDeviceToHost);
+    }
+    g_gemm256 = mode; e.out = o0;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
+    hipEventRecord(e1, s); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    *us_out = ms * 1000.f / iters;
+    g_gemm256 = saved;
+    const int rc = hipGetLastError() == hipSuccess ? 0 : -1;
+    hipFree(A); hipFree(Wt); hipFree(zeros); hipFree(o0); if (o1) hipFree(o1); hipFree(md);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    return rc;
+}

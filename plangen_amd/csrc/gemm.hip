@@ -16,90 +16,7 @@
 //  gemm_f32   : plain fp32 tiled GEMM (PG_F32 parity mode); same loaders/epilogue.
 #include "kernels.h"
 
-// ------------------------------------------------------------------------------- loaders
-template <typename T>
-struct PlainLoader {
-    const T* A; long lda; int M;
-    const T* rowp[4];
-    __device__ __forceinline__ void init(int i, int m) { rowp[i] = A + (long)(m < M ? m : M - 1) * lda; }
-    __device__ __forceinline__ void set_ktile(int) {}
-    __device__ __forceinline__ const T* ptr(int i, int k) const { return rowp[i] + k; }
-    __device__ __forceinline__ float elem(int m, int k) const { return m < M ? ET<T>::ld(A + (long)m * lda + k) : 0.f; }
-};
-
-// 3x3 conv, pad 1 (stride 1, optional nearest-2x upsample of the input) or the encoder's
-// stride-2 / pad (0,1,0,1) form.  Input NHWC [B,Hi,Wi,Cin]; output pixel m = (b, y, x)
-// over [B,Ho,Wo]; K index = tap*Cin + ci.
-template <typename T>
-struct ConvLoader {
-    const T* X; const T* zeros; int Hi, Wi, Cin, up, stride2, Ho, Wo, M;
-    const T* img[4]; int yy[4], xx[4];
-    const T* cur[4];               // source pixel of the CURRENT tap for each staging slot (nullptr = halo -> zeros)
-    int ci0, cur_tap;
-    __device__ __forceinline__ void decode(int m, int& b, int& y, int& x) const {
-        x = m % Wo; int t = m / Wo; y = t % Ho; b = t / Ho;
-    }
-    __device__ __forceinline__ void init(int i, int m) {
-        if (m >= M) m = M - 1;
-        int b, y, x; decode(m, b, y, x);
-        img[i] = X + (long)b * Hi * Wi * Cin; yy[i] = y; xx[i] = x;
-        cur_tap = -1;
-    }
-    __device__ __forceinline__ bool src_yx(int y, int x, int ddy, int ddx, int& sy, int& sx) const {
-        if (stride2) { sy = 2 * y + ddy; sx = 2 * x + ddx; return sy < Hi && sx < Wi; }
-        const int oy = y + ddy - 1, ox = x + ddx - 1;
-        sy = oy >> up; sx = ox >> up;
-        return oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
-    }
-    // K tiles arrive in increasing k; the halo test and the 64-bit address are recomputed only when
-    // the tap changes (every Cin/64 tiles).  Cin is a power of two (64..512): shift / mask.
-    __device__ __forceinline__ void set_ktile(int k0) {
-        const int lc = 31 - __builtin_clz(Cin);
-        const int tap = k0 >> lc; ci0 = k0 & (Cin - 1);
-        if (tap != cur_tap) {
-            cur_tap = tap;
-            const int dy = tap / 3, dx = tap - dy * 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int sy, sx;
-                cur[i] = src_yx(yy[i], xx[i], dy, dx, sy, sx) ? img[i] + ((long)sy * Wi + sx) * Cin : nullptr;
-            }
-        }
-    }
-    // k = k-tile base + chunk offset (chunk of 8 elements inside one tap because Cin % 64 == 0)
-    __device__ __forceinline__ const T* ptr(int i, int k) const {
-        const int koff = k & 63;
-        return cur[i] ? cur[i] + ci0 + koff : zeros + koff;
-    }
-    __device__ __forceinline__ float elem(int m, int k) const {
-        if (m >= M) return 0.f;
-        int b, y, x; decode(m, b, y, x);
-        const int tap = k / Cin, ci = k - tap * Cin, ddy = tap / 3, ddx = tap - ddy * 3;
-        int sy, sx;
-        if (!src_yx(y, x, ddy, ddx, sy, sx)) return 0.f;
-        return ET<T>::ld(X + (((long)b * Hi + sy) * Wi + sx) * Cin + ci);
-    }
-};
-
-// ------------------------------------------------------------------------------- epilogue
-template <typename T>
-struct Epi {
-    GemmEpi e; int M, N;
-    __device__ __forceinline__ void operator()(long coff, long roff, int row, int col, float v) const {
-        if (row >= M || col >= N) return;
-        v *= e.scale;
-        if (e.bias_n) v += e.bias_n[col];
-        if (e.bias_m) v += e.bias_m[row];
-        if (e.residual) {
-            const long ldr = e.ldr ? e.ldr : e.ldc;
-            const long ro = roff + (long)row * ldr + col;
-            v += e.res_f32 ? ((const float*)e.residual)[ro] : ET<T>::ld((const T*)e.residual + ro);
-        }
-        if (e.act == 1) v = gelu_erf(v);
-        const long o = coff + (long)row * e.ldc + col;
-        if (e.out_f32) ((float*)e.out)[o] = v; else ET<T>::st((T*)e.out + o, v);
-    }
-};
+#include "gemm_common.h"
 
 // ------------------------------------------------------------------------------- big MFMA GEMM
 #define BIG_BM 128
@@ -107,14 +24,6 @@ struct Epi {
 #define BIG_BK 64
 #define BIG_TILE_BYTES (128 * 64 * 2)   // 16 KiB per operand tile
 #define BIG_LDS (4 * BIG_TILE_BYTES)    // A[2] + B[2]
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
-    // LDS destination = wave-uniform base + lane*16 (hardware); source address is per lane.
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_wave_base, 16, 0, 0);
-}
 
 template <class AL, class EP>
 __global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __restrict__ W, long ldb,
@@ -210,14 +119,6 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __r
                 ep(coff, roff, m0 + wm * 64 + mt * 16 + g * 4 + r, n0 + wn * 64 + nt * 16 + lr, acc[mt][nt][r]);
 }
 
-// loaders need a batch offset hook
-template <typename T> struct PlainLoaderB : PlainLoader<T> {
-    __device__ __forceinline__ void A_offset(long off) { this->A += off; }
-};
-template <typename T> struct ConvLoaderB : ConvLoader<T> {
-    __device__ __forceinline__ void A_offset(long off) { this->X += off; }
-};
-
 // ------------------------------------------------------------------------------- fp32 GEMM
 template <class AL, class EP>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(AL al, const float* __restrict__ W, long ldb,
@@ -266,6 +167,7 @@ template <typename T> struct BigDispatch;
 template <> struct BigDispatch<bf16> {
     static void run(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e,
                     int M, int N, int K, int batch, int batch2, long strideB2) {
+        if (gemm256_try(s, a, W, ldb, strideB, e, M, N, K, batch, batch2, strideB2)) return;
         Epi<bf16> ep{e, M, N};
         const int ntm = (M + BIG_BM - 1) / BIG_BM, ntn = (N + BIG_BN - 1) / BIG_BN;
         dim3 grid(ntm * ntn, batch, batch2), block(256);
@@ -337,7 +239,7 @@ __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)
     for (int v = tid; v < MT * 16 * V4; v += NTH) {
         const int row = v / V4, c4 = (v % V4) * 4;
         const int m = mbase + row, n = nbase + c4;
-        if (m < M && n < N) *(f32x4*)(o + (long)m * N + n) = *(const f32x4*)(t + row * LD + c4);
+        if (m < M && n < N) __builtin_nontemporal_store(*(const f32x4*)(t + row * LD + c4), (f32x4*)(o + (long)m * N + n));
     }
 }
 

@@ -37,6 +37,11 @@ template <typename T>
 void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strideB,
                  const GemmEpi& e, int M, int N, int K, int batch, int batch2 = 1, long strideB2 = 0);
 
+// 256x256 eight-phase kernel (gemm256.hip); returns false when the shape should stay on the 128x128 kernel.
+bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e, int M, int N, int K,
+                 int batch, int batch2, long strideB2);
+extern int g_gemm256;
+
 // Skinny weight-streaming GEMM (decode): x [M,K] bf16 (M <= 128 per launch block-row),
 // W [N,K] bf16, out fp32 [S,M,N] split-K partial slabs (consumer kernels reduce over S).
 // Returns S.  N % 16 == 0, K % 128 == 0.

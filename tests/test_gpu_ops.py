@@ -90,3 +90,49 @@ def test_groupnorm_swish(tiny_cfg, tiny_weights, dtype, C, swish):
     out = e.op_groupnorm(x.permute(0, 2, 3, 1).contiguous(), gamma, beta, swish).float().cpu().permute(0, 3, 1, 2)
     tol = 2e-5 if dtype == "f32" else 2e-2
     assert (out - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 2048, 512), (8200, 2040, 192), (13000, 1024, 128), (32768, 512, 1024)])
+def test_gemm_256_tile_path(tiny_cfg, tiny_weights, M, N, K):
+    """Shapes that fill >= 200 tiles of 256x256 go through the persistent eight-phase kernel
+    (gemm256.hip); ragged M / N exercise the clamped staging rows and the masked epilogue.
+    Checked against fp64 and bit-for-bit against the 128x128 kernel (same K order)."""
+    e = _eng(tiny_cfg, tiny_weights, "bf16")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _round(torch.randn(M, K, generator=g), "bf16")
+    w = _round(torch.randn(N, K, generator=g) * torch.linspace(0.5, 2.0, N)[:, None], "bf16")
+    e.set_option("gemm256", 1)
+    out = e.op_gemm(a, w, 2).cpu()
+    e.set_option("gemm256", 0)
+    out128 = e.op_gemm(a, w, 2).cpu()
+    e.set_option("gemm256", 1)
+    ref = a.double() @ w.double().t()
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-4 * ref.abs().max().item() + 1e-4, err
+    assert torch.equal(out, out128)
+
+
+@pytest.mark.parametrize("up,stride2,res,B,Hs,Cin,Cout", [(0, 0, True, 6, 96, 64, 256), (1, 0, False, 6, 48, 128, 256),
+                                                         (0, 1, False, 8, 192, 64, 256), (0, 0, False, 3, 96, 64, 512)])
+def test_conv3x3_256_tile_path(tiny_cfg, tiny_weights, up, stride2, res, B, Hs, Cin, Cout):
+    e = _eng(tiny_cfg, tiny_weights, "bf16")
+    g = torch.Generator().manual_seed(11 + up + 2 * stride2 + Cin)
+    x = _round(torch.randn(B, Cin, Hs, Hs, generator=g), "bf16")
+    w = _round(torch.randn(Cout, Cin, 3, 3, generator=g) / 24, "bf16")
+    b = torch.randn(Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, b, stride=2) if stride2 else F.conv2d(xin, w, b, padding=1)
+    r = None
+    if res:
+        r = _round(torch.randn(ref.shape, generator=g), "bf16")
+        ref = ref + r
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    rn = None if r is None else r.permute(0, 2, 3, 1).contiguous()
+    e.set_option("gemm256", 1)
+    out = e.op_conv3x3(xn, w, b, rn, up, stride2)
+    e.set_option("gemm256", 0)
+    out128 = e.op_conv3x3(xn, w, b, rn, up, stride2)
+    e.set_option("gemm256", 1)
+    assert torch.equal(out, out128)
+    o = out.float().cpu().permute(0, 3, 1, 2)
+    assert (o - ref).abs().max() < 2e-2 * ref.abs().max()
