@@ -40,7 +40,7 @@
 
 __device__ __forceinline__ void g2_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <class AL, class EP, bool STAGGER, int ABL = 0>
+template <class AL, class EP, bool STAGGER, int ABL = 0, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                                                      long strideA2, long strideB2, EP ep, int M, int N, int K, int ntm, int ntn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,8 +134,62 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         g2_barrier();
+        if constexpr (SCHED == 1) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                b0[nt][0] = *(const bf16x8*)(smem + boff0 + nt * 2048);
+                b0[nt][1] = *(const bf16x8*)(smem + boff1 + nt * 2048);
+            }
+        }
         if (STAGGER && wr == 1) g2_barrier();
 
+        if constexpr (SCHED == 1) {
+            // Variant: the 4 HB0 fragment reads move from phase 1 (12 ds_reads) to phase 4 of the PREVIOUS
+            // K tile (0 reads) into the register set B1 just vacated -> 8/4/8/4 reads per phase; the two
+            // B register sets swap roles every K tile.  Counted waits: P1 vmcnt(8), P2 vmcnt(8),
+            // P3 vmcnt(6) (retires HB0(kt+1), issued 3 half-tiles earlier, and HA0(kt+1) before it), P4 none.
+#define G2_TILE(KT, BX, BY)                                                                                 \
+            {                                                                                               \
+                const char* buf = smem + ((KT) & 1) * G2_BUF;                                               \
+                const char* nbuf = smem + (((KT) + 1) & 1) * G2_BUF;                                        \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                          \
+                    a[mt][0] = *(const bf16x8*)(buf + aoff0 + mt * 2048);                                   \
+                    a[mt][1] = *(const bf16x8*)(buf + aoff1 + mt * 2048);                                   \
+                }                                                                                           \
+                stage_B(1, (KT) + 1);                                                                       \
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+                G2_MFMA_SECTION(0, BX, 0)                                                                   \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                          \
+                    BY[nt][0] = *(const bf16x8*)(buf + G2_HALF + boff0 + nt * 2048);                        \
+                    BY[nt][1] = *(const bf16x8*)(buf + G2_HALF + boff1 + nt * 2048);                        \
+                }                                                                                           \
+                stage_A(1, (KT) + 1);                                                                       \
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+                G2_MFMA_SECTION(0, BY, 1)                                                                   \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                          \
+                    a[mt][0] = *(const bf16x8*)(buf + G2_HALF + aoff0 + mt * 2048);                         \
+                    a[mt][1] = *(const bf16x8*)(buf + G2_HALF + aoff1 + mt * 2048);                         \
+                }                                                                                           \
+                stage_A(0, (KT) + 2);                                                                       \
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                            \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+                G2_MFMA_SECTION(1, BY, 1)                                                                   \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                          \
+                    BY[nt][0] = *(const bf16x8*)(nbuf + boff0 + nt * 2048);                                 \
+                    BY[nt][1] = *(const bf16x8*)(nbuf + boff1 + nt * 2048);                                 \
+                }                                                                                           \
+                stage_B(0, (KT) + 2);                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+                G2_MFMA_SECTION(1, BX, 0)                                                                   \
+            }
+            for (int kt = 0; kt < nk; kt += 2) {
+                G2_TILE(kt, b0, b1)
+                if (kt + 1 < nk) G2_TILE(kt + 1, b1, b0)
+            }
+#undef G2_TILE
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             const char* buf = smem + (kt & 1) * G2_BUF;
             // ---- phase 1: quadrant (0,0): fragments of HB0 and HA0; stage HB1(kt+1)
@@ -216,6 +270,13 @@ static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long stride
             (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
             hipLaunchKernelGGL(kfn, grid, block, G2_LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
         }
+        return;
+    }
+    if (g_gemm256 == 3) {
+        auto kfn = gemm256_kernel<AL, Epi<bf16>, true, 0, 1>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS); attr = true; }
+        hipLaunchKernelGGL(kfn, grid, block, G2_LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
         return;
     }
     if (g_gemm256 == 2) {
