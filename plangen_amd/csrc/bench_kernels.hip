@@ -119,8 +119,11 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     if (verify) {
         hipMalloc((void**)&o1, (long)M * N * 4);
         g_gemm256 = 0; e.out = o1; launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
-        g_gemm256 = mode ? mode : 1; e.out = o0; hipMemsetAsync(o0, 0xff, (long)M * N * 4, s); launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
-        hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, s, o0, o1, (long)M * N, md);
+        // race screen: `verify` independent launches, each compared element-wise with the 128x128 result
+        for (int v = 0; v < verify; ++v) {
+            g_gemm256 = mode ? mode : 1; e.out = o0; hipMemsetAsync(o0, 0xff, (long)M * N * 4, s); launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
+            hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, s, o0, o1, (long)M * N, md);
+        }
         hipStreamSynchronize(s);
         hipMemcpy(maxdiff_out, md, 4, hipMemcpyDeviceToHost);
     }

@@ -1300,6 +1300,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
     if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
     if (!strcmp(key, "gemm256")) { g_gemm256 = (int)value; return PG_OK; }
+    if (!strcmp(key, "attn_waves")) { g_attn_waves = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
     if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }

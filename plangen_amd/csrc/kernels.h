@@ -41,6 +41,7 @@ void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strid
 bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e, int M, int N, int K,
                  int batch, int batch2, long strideB2);
 extern int g_gemm256;
+extern int g_attn_waves;
 
 // Skinny weight-streaming GEMM (decode): x [M,K] bf16 (M <= 128 per launch block-row),
 // W [N,K] bf16, out fp32 [S,M,N] split-K partial slabs (consumer kernels reduce over S).

@@ -312,12 +312,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qbuf, T
 // cached K/V (non-temporal 16-byte loads: the cache is read exactly once per step) and merges
 // the new key, which never leaves LDS, as one more online-softmax state.  Replaces
 // rope_kv_kernel + attn_kernel (one launch and the q round trip less per layer).
-template <typename T, int UN>
-__global__ __launch_bounds__(256) void attn_decode_fused_kernel(const float* __restrict__ qkv, int S, long slab,
+template <typename T, int UN, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float* __restrict__ qkv, int S, long slab,
                                                                T* __restrict__ obuf, T* __restrict__ kc, T* __restrict__ vc,
                                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                                SeqState st, int nh, int slots, int max_pos, float scale) {
-    constexpr int EPV = ET<T>::EPV, LPK = 128 / EPV, KPI = 64 / LPK, NST = 4 * KPI;
+    constexpr int EPV = ET<T>::EPV, LPK = 128 / EPV, KPI = 64 / LPK, NST = NW * KPI;
     __shared__ float s_o[NST][128];
     __shared__ float s_m[NST], s_l[NST];
     __shared__ __attribute__((aligned(16))) float s_q[128];
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const float* __r
     // every uncond row of the batch and should stay in L2).
     auto run = [&](const T* kb, const T* vb, int k0, int k1, auto ntl) {
         constexpr bool NTL = decltype(ntl)::value;
-        for (int base = k0 + w * KPW; base < k1; base += 4 * KPW) {
+        for (int base = k0 + w * KPW; base < k1; base += NW * KPW) {
             u32x4 kv[UN], vv[UN];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -444,13 +444,19 @@ __global__ __launch_bounds__(256) void attn_decode_fused_kernel(const float* __r
         ET<T>::st(obuf + (long)row * HD + head * 128 + tid, num / den);
     }
 }
+int g_attn_waves = 0;        // pg_set_option("attn_waves", 4) pins the 4-wave block (A/B)
 template <typename T>
 void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc,
                               const float* cos_t, const float* sin_t, SeqState st, int M, int nh, int slots,
                               int max_pos, float scale) {
     if (M <= 0) return;
-    hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
-                       st, nh, slots, max_pos, scale);
+    // few (row, head) blocks (small batch): eight waves per block keep 2x the K/V bytes in flight per CU
+    if (M * nh <= 512 && g_attn_waves != 4)
+        hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8, 8>), dim3(nh, M), dim3(512), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
+                           st, nh, slots, max_pos, scale);
+    else
+        hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8, 4>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
+                           st, nh, slots, max_pos, scale);
 }
 template void launch_attn_decode_fused<float>(hipStream_t, const float*, int, long, float*, float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
 template void launch_attn_decode_fused<bf16>(hipStream_t, const float*, int, long, bf16*, bf16*, bf16*, const float*, const float*, SeqState, int, int, int, int, float);
