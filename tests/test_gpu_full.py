@@ -161,3 +161,59 @@ def test_flash_prefill_matches_streaming_attention():
         real[r, :p] = False
     d = (outs[0] - outs[1])[real].abs().max()
     assert d < 0.03 * outs[1][real].abs().max(), d
+
+
+def test_mmu_and_uni_2stage_full_size_properties():
+    """BASELINE configs[2] / configs[4] at Janus-Pro-1B + SigLIP-L/16-384 shapes: image -> vision tower ->
+    aligner -> scatter -> greedy text decode (mmu), then text -> image tokens on the same handle
+    (uni_2stage).  Size-independent properties: batch invariance of the vision tower and of the greedy
+    ids, determinism across calls, EOS padding, VQ encode -> decode_code round trip shape/finite."""
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    from plangen_amd.system import System
+    cfg = PlanGenConfig.janus_pro_1b()
+    L = cfg.vit_tokens + 16
+    e = Engine(cfg, dtype="bf16", max_rows=4, max_prompt=L, max_new=32, max_images=2, with_lm_head=True,
+               with_vq_encoder=True, with_vision=True, max_vision_images=3)
+    e.init_synthetic(seed=0)
+    sysm = System(cfg, e)
+    g = torch.Generator().manual_seed(5)
+    pix = torch.rand(3, 3, cfg.vit_img, cfg.vit_img, generator=g) * 2 - 1
+    f3 = e.vision_encode(pix)
+    f2 = e.vision_encode(pix[:2])
+    assert f3.shape == (3, cfg.vit_tokens, cfg.hidden) and torch.isfinite(f3.float()).all()
+    assert torch.equal(f3[:2], f2)                                   # an image's features ignore its batch mates
+    assert f3.float().std() > 1e-3
+
+    B, P = 2, cfg.vit_tokens
+    ids = torch.full((B, L), cfg.pad_id, dtype=torch.int64)
+    seq_mask = torch.zeros((B, L), dtype=torch.bool)
+    attn = torch.zeros((B, L), dtype=torch.int32)
+    for b, ntxt in enumerate((9, 4)):
+        n = 1 + P + ntxt + 1
+        ids[b, L - n:] = torch.randint(10, 100000, (n,), generator=g)
+        seq_mask[b, L - n + 1: L - n + 1 + P] = True
+        attn[b, L - n:] = 1
+    emb_mask = torch.ones((B, 1, P), dtype=torch.bool)
+    emb = sysm.vl_gpt.prepare_inputs_embeds(input_ids=ids, pixel_values=pix[:2, None], images_seq_mask=seq_mask,
+                                            images_emb_mask=emb_mask)
+    assert emb.shape == (B, L, cfg.hidden)
+    out = sysm.x2t(emb, attn.to(e.device), max_new_tokens=12)
+    out2 = sysm.x2t(emb, attn.to(e.device), max_new_tokens=12)
+    assert out.dtype == torch.int64 and out.shape[0] == B and out.shape[1] <= 12
+    assert torch.equal(out, out2)
+    one = sysm.x2t(emb[1:], attn[1:].to(e.device), max_new_tokens=12)   # row 1 alone: same ids (left-pad skipping)
+    n = min(one.shape[1], out.shape[1])
+    assert torch.equal(one[0, :n], out[1, :n])
+    assert ((out >= 0) & (out < cfg.vocab)).all()
+
+    # stage 2 on the same handle: a 2-image CFG batch, 8 image tokens, then VQ encode of a decoded image
+    ids2, pad2 = _prompts(2, 48, [40, 17], seed=3)
+    e.prefill(ids2, pad2, position_mode=0)
+    toks = e.decode_image_tokens(T=8, cfg_weight=5.0, temperature=0.0, seed=0)
+    assert toks.shape == (2, 8) and ((toks >= 0) & (toks < cfg.img_vocab)).all()
+    codes = torch.randint(0, cfg.img_vocab, (1, cfg.img_tokens), generator=g).int()
+    img = e.vq_decode(codes)
+    idx = e.vq_encode(img.float().clamp(-1, 1))
+    assert idx.numel() == cfg.img_tokens and ((idx >= 0) & (idx < cfg.img_vocab)).all()
+    del e
