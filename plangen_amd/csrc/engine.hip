@@ -114,7 +114,9 @@ struct pg_engine {
     hipStream_t istream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr, ev_v0 = nullptr, ev_v1 = nullptr;
     hipGraphExec_t gexec = nullptr; std::vector<int64_t> gkey;
-    bool use_graph = true; bool time_attn = false; bool fuse_rope = true;
+    hipGraphExec_t gexec_txt = nullptr; std::vector<int64_t> gkey_txt;      // text-decode step (lm_head + argmax + stack)
+    void drop_graphs() { if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; } if (gexec_txt) { (void)hipGraphExecDestroy(gexec_txt); gexec_txt = nullptr; } }
+    bool use_graph = true; bool time_attn = false; bool fuse_rope = true; bool force_swiglu = true;
     std::vector<hipEvent_t> attn_ev; size_t attn_ev_used = 0; std::vector<double> attn_ev_bytes;
     pg_timing timing{};
     bool have_decode_t = false, have_prefill_t = false, have_vq_t = false;
@@ -504,7 +506,7 @@ int pg_engine::create() {
 void pg_engine::destroy() {
     (void)hipSetDevice(dev);
     (void)hipDeviceSynchronize();
-    if (gexec) (void)hipGraphExecDestroy(gexec);
+    drop_graphs();
     for (void* p : allocs) (void)hipFree(p);
     if (stage_dev) (void)hipFree(stage_dev);
     if (h_stage) (void)hipHostFree(h_stage);
@@ -693,7 +695,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
         bool fused = false;
         if constexpr (std::is_same<T, bf16>::value) {
             // decode: SwiGLU gate fused into the gate|up GEMM epilogue (S = 1, no slab, no extra kernel)
-            if (sk && M <= 512 && Hh % 128 == 0 && skinny_pick_splits(2 * I, Hh, M) == 1)
+            if (sk && M <= 512 && Hh % 128 == 0 && (force_swiglu || skinny_pick_splits(2 * I, Hh, M) == 1))   // fused wins at every M (B=4/8/16: -2..3 % loop time)
                 fused = launch_gemm_skinny_swiglu(s, (const bf16*)xn, (const bf16*)ly.wgu, (bf16*)hbuf, M, 2 * I, Hh, (const bf16*)ly.wgu_t);
         }
         if (!fused) {
@@ -960,20 +962,52 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
     ta.any_unfinished = d_anyunf; ta.embed_table = embed; ta.x = x; ta.H = H(); ta.n_dec = d_ndec;
     std::vector<int32_t> flags(1024);
     int checked = 0, done_len = -1;
-    for (int step_i = 0; step_i < max_new; ++step_i) {
-        if (bf) gemm_llm<bf16>(s, (const bf16*)hfin, (const bf16*)lm_head, B, cfg.vocab, H(), true, lm_head_t);
-        else gemm_llm<float>(s, (const float*)hfin, (const float*)lm_head, B, cfg.vocab, H(), true);
+    // one step = lm_head GEMM -> argmax / EOS bookkeeping (device step counter) -> the stack on the new
+    // token's embedding.  Like the image loop it is captured once and replayed; every 8th step the
+    // any-unfinished flags come back to the host (HF generate stops when every row has emitted EOS).
+    hipStream_t ws = s;
+    if (use_graph) {
+        HIPCHK(hipEventRecord(ev_in, s));
+        HIPCHK(hipStreamWaitEvent(istream, ev_in, 0));
+        ws = istream;
+    }
+    auto iteration = [&](bool with_forward) {
+        if (bf) gemm_llm<bf16>(ws, (const bf16*)hfin, (const bf16*)lm_head, B, cfg.vocab, H(), true, lm_head_t);
+        else gemm_llm<float>(ws, (const float*)hfin, (const float*)lm_head, B, cfg.vocab, H(), true);
         ta.logits_partial = part; ta.S = S_last; ta.slab = slab_last;
-        launch_text_argmax(s, ta, B);
+        launch_text_argmax(ws, ta, B);
+        if (with_forward) forward_decode(ws);
+    };
+    for (int step_i = 0; step_i < max_new; ++step_i) {
         const bool last = step_i == max_new - 1;
-        if (!last) { forward_decode(s); n_dec_host++; }
+        if (use_graph && !last && step_i > 0) {
+            std::vector<int64_t> key = {R, (int64_t)bf, eos, min_new, max_new, (int64_t)out, (int64_t)fuse_rope, (int64_t)shared_len};
+            if (!gexec_txt || key != gkey_txt) {
+                if (gexec_txt) { (void)hipGraphExecDestroy(gexec_txt); gexec_txt = nullptr; }
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal));
+                iteration(true);
+                HIPCHK(hipStreamEndCapture(ws, &g));
+                HIPCHK(hipGraphInstantiate(&gexec_txt, g, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(g);
+                gkey_txt = key;
+            }
+            HIPCHK(hipGraphLaunch(gexec_txt, ws));
+        } else {
+            iteration(!last);
+        }
+        if (!last) n_dec_host++;
         if (last || (step_i & 7) == 7) {
-            HIPCHK(hipMemcpyAsync(flags.data(), d_anyunf, 1024 * 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(hipMemcpyAsync(flags.data(), d_anyunf, 1024 * 4, hipMemcpyDeviceToHost, ws));
+            HIPCHK(hipStreamSynchronize(ws));
             for (; checked <= step_i; ++checked)
                 if (flags[(checked + 1) & 1023] == 0) { done_len = checked + 1; break; }
             if (done_len >= 0) break;
         }
+    }
+    if (ws != s) {
+        HIPCHK(hipEventRecord(ev_out, ws));
+        HIPCHK(hipStreamWaitEvent(s, ev_out, 0));
     }
     if (done_len < 0) done_len = max_new;
     if (out_len) *out_len = done_len;
@@ -1295,15 +1329,16 @@ int pg_get_timing(pg_handle h, pg_timing* out) {
 int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!h || !key) return PG_ERR_ARG;
     if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
+    if (!strcmp(key, "force_swiglu")) { h->force_swiglu = value != 0; h->drop_graphs(); return PG_OK; }
     if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
     if (!strcmp(key, "share_uncond")) { h->share_uncond = value != 0; return PG_OK; }
     if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
     if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
     if (!strcmp(key, "gemm256")) { g_gemm256 = (int)value; return PG_OK; }
-    if (!strcmp(key, "attn_waves")) { g_attn_waves = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
-    if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
-    if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
-    if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; } return PG_OK; }
+    if (!strcmp(key, "attn_waves")) { g_attn_waves = (int)value; h->drop_graphs(); return PG_OK; }
+    if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; h->drop_graphs(); return PG_OK; }
+    if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->drop_graphs(); return PG_OK; }
+    if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; h->drop_graphs(); return PG_OK; }
     h->err = std::string("unknown option ") + key;
     return PG_ERR_ARG;
 }
