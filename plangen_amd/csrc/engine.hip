@@ -1329,6 +1329,11 @@ int pg_get_timing(pg_handle h, pg_timing* out) {
 int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!h || !key) return PG_ERR_ARG;
     if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
+    if (!strncmp(key, "split_target_", 13)) {
+        extern int g_split_target_small, g_split_target_mid, g_split_target_big;
+        (key[13] == 's' ? g_split_target_small : key[13] == 'm' ? g_split_target_mid : g_split_target_big) = (int)value;
+        h->drop_graphs(); return PG_OK;
+    }
     if (!strcmp(key, "force_swiglu")) { h->force_swiglu = value != 0; h->drop_graphs(); return PG_OK; }
     if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
     if (!strcmp(key, "share_uncond")) { h->share_uncond = value != 0; return PG_OK; }

@@ -375,9 +375,11 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16* __restr
 // 256 CUs streaming.  Measured on MI355X (tools/skinny_sweep.py): at M = 128 fewer, fatter
 // blocks win (slab traffic grows with S), at M <= 32 more, thinner ones do; S is restricted to
 // chunk counts the unrolled kernel is instantiated for.
+int g_split_target_small = 128;   // pg_set_option("split_target_{small,mid,big}", n): block-count targets at M < 48 / < 96 / >= 96
+int g_split_target_mid = 256, g_split_target_big = 128;
 int skinny_pick_splits(int N, int K, int M) {
     const int nblk = (N + 63) / 64, nchunks = K / SK_BK;
-    const int target = M >= 96 ? 128 : (M >= 48 ? 256 : 512);   // GEMM+consumer optimum (sweep "+n" columns)
+    const int target = M >= 96 ? g_split_target_big : (M >= 48 ? g_split_target_mid : g_split_target_small);   // GEMM+consumer optimum (sweep "+n" columns)
     int best = 1;
     for (int S = 1; S <= nchunks; ++S) {
         if (nchunks % S) continue;
