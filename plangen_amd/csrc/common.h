@@ -108,3 +108,68 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t a, uint64_t
     z = z ^ (z >> 31);
     return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
 }
+
+// One row of (split-K reduce + residual add + RMSNorm) by a 256-thread block (rmsnorm_kernel and the
+// norm blocks of the fused norm+GEMM launch share it).  ``red``: >= 4 floats of LDS.
+template <typename T, int NV, bool SC1 = false>
+__device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const float* __restrict__ partial,
+                                            int S, long slab, const T* __restrict__ w,
+                                            T* __restrict__ xn, int H, float eps, float* red) {
+    const int tid = threadIdx.x;
+    float* xr = x + (long)m * H;
+    f32x4 v[NV];
+    float ss = 0.f;
+    // norm weights first: independent of the reduction, so the row costs ONE memory round trip
+    u32x2 wv2[NV]; f32x4 wv4[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid * 4 + j * 1024;
+        if (xn && i < H) { if constexpr (sizeof(T) == 2) wv2[j] = *(const u32x2*)(w + i); else wv4[j] = *(const f32x4*)(w + i); }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid * 4 + j * 1024;
+        v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < H) {
+            v[j] = *(const f32x4*)(xr + i);
+            // slab loads in batches of 8 independent requests (a plain ``for s`` loop is not unrolled
+            // by hipcc for runtime S and degenerates into S dependent round trips)
+            const float* pp = partial + (long)m * H + i;
+            for (int s0 = 0; s0 < S; s0 += 8) {
+                f32x4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = s0 + u < S ? s0 + u : S - 1;
+                    t[u] = *(const f32x4*)(pp + (long)s * slab);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (s0 + u < S) v[j] += t[u];
+            }
+            if (S > 0) *(f32x4*)(xr + i) = v[j];
+            ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+        }
+    }
+    ss = block_sum<4>(ss, red);
+    if (!xn) return;
+    const float rstd = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid * 4 + j * 1024;
+        if (i < H) {
+            float o[4];
+            if constexpr (sizeof(T) == 2) {
+                const u32x2 wv = wv2[j];
+                o[0] = bf16_lo(wv.x) * (v[j].x * rstd); o[1] = bf16_hi(wv.x) * (v[j].y * rstd);
+                o[2] = bf16_lo(wv.y) * (v[j].z * rstd); o[3] = bf16_hi(wv.y) * (v[j].w * rstd);
+                u32x2 ov; ov.x = pack_bf16x2(o[0], o[1]); ov.y = pack_bf16x2(o[2], o[3]);
+                // SC1: write-through (device-scope) store: the row is consumed by other XCDs inside this launch
+                if constexpr (SC1) __hip_atomic_store((uint64_t*)(xn + (long)m * H + i), ((uint64_t)ov.y << 32) | ov.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *(u32x2*)(xn + (long)m * H + i) = ov;
+            } else {
+                const f32x4 wv = wv4[j];
+                f32x4 ov = {wv.x * (v[j].x * rstd), wv.y * (v[j].y * rstd), wv.z * (v[j].z * rstd), wv.w * (v[j].w * rstd)};
+                *(f32x4*)(xn + (long)m * H + i) = ov;
+            }
+        }
+    }
+}

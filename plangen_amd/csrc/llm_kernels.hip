@@ -39,54 +39,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
                                                      int S, long slab, const T* __restrict__ w,
                                                      T* __restrict__ xn, int H, float eps) {
     __shared__ float red[4];
-    const int m = blockIdx.x, tid = threadIdx.x;
-    float* xr = x + (long)m * H;
-    f32x4 v[NV];
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = tid * 4 + j * 1024;
-        v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (i < H) {
-            v[j] = *(const f32x4*)(xr + i);
-            // slab loads in batches of 8 independent requests (a plain ``for s`` loop is not unrolled
-            // by hipcc for runtime S and degenerates into S dependent round trips)
-            const float* pp = partial + (long)m * H + i;
-            for (int s0 = 0; s0 < S; s0 += 8) {
-                f32x4 t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int s = s0 + u < S ? s0 + u : S - 1;
-                    t[u] = *(const f32x4*)(pp + (long)s * slab);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) if (s0 + u < S) v[j] += t[u];
-            }
-            if (S > 0) *(f32x4*)(xr + i) = v[j];
-            ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-        }
-    }
-    ss = block_sum<4>(ss, red);
-    if (!xn) return;
-    const float rstd = rsqrtf(ss / (float)H + eps);
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = tid * 4 + j * 1024;
-        if (i < H) {
-            float o[4];
-            if constexpr (sizeof(T) == 2) {
-                const u32x2 wv = *(const u32x2*)(w + i);
-                o[0] = bf16_lo(wv.x) * (v[j].x * rstd); o[1] = bf16_hi(wv.x) * (v[j].y * rstd);
-                o[2] = bf16_lo(wv.y) * (v[j].z * rstd); o[3] = bf16_hi(wv.y) * (v[j].w * rstd);
-                u32x2 ov; ov.x = pack_bf16x2(o[0], o[1]); ov.y = pack_bf16x2(o[2], o[3]);
-                *(u32x2*)(xn + (long)m * H + i) = ov;
-            } else {
-                const f32x4 wv = *(const f32x4*)(w + i);
-                f32x4 ov = {wv.x * (v[j].x * rstd), wv.y * (v[j].y * rstd), wv.z * (v[j].z * rstd), wv.w * (v[j].w * rstd)};
-                *(f32x4*)(xn + (long)m * H + i) = ov;
-            }
-        }
-    }
+    rmsnorm_row<T, NV>(blockIdx.x, x, partial, S, slab, w, xn, H, eps, red);
 }
 template <typename T>
 void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
