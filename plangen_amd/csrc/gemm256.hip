@@ -1,4 +1,5 @@
-// 256x256x64 bf16 MFMA GEMM for gfx950, eight waves (2 x 4), 128 KiB of LDS, one block per CU.
+// 256x256x64 (and 512x128x64) bf16 MFMA GEMM for gfx950, eight waves, 128 / 160 KiB of LDS, one persistent
+// block per CU.
 //
 //   C[M,N] = A[M,K] . W[N,K]^T      (same loaders / epilogue as gemm.hip's 128x128 kernel)
 //
@@ -30,19 +31,25 @@
 //   its load section: LDS reads and address arithmetic hide under the other wave's MFMAs.
 // * K tiles past the end are staged from the last valid tile (never read): the loop is
 //   branch-free and the vmcnt counts stay exact.
+// * Geometry is a template (WM x WN waves, 128x64 of C per wave): 2x4 = 256x256 (A half-tile 16 KiB = 2 loads
+//   per thread, W half-tile 16 KiB = 2 loads, counted wait vmcnt(8)) is what runs; 4x2 = 512x128 (A half-tile
+//   32 KiB = 4 loads, W half-tile 8 KiB = 1 load, vmcnt(10), all 160 KiB of LDS) is correct but slower (below).
+//   Any 4 consecutive half-tiles of the stream are two A and two W halves, hence one count per geometry.
 #include <type_traits>
 #include "gemm_common.h"
 
 #define G2_BK 64
-#define G2_HALF 16384
-#define G2_BUF (4 * G2_HALF)
-#define G2_LDS (2 * G2_BUF)
 
 __device__ __forceinline__ void g2_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <class AL, class EP, bool STAGGER, int ABL = 0, int SCHED = 0>
+template <class AL, class EP, int WM, int WN>
 __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                                                      long strideA2, long strideB2, EP ep, int M, int N, int K, int ntm, int ntn) {
+    static_assert(WM * WN == 8 && (WN == 2 || WN == 4), "eight waves, 128x64 of C each");
+    constexpr int BM = WM * 128, BN = WN * 64;
+    constexpr int AH = WM * 64 * 128, BH = WN * 32 * 128;        // bytes per A / W half-tile
+    constexpr int BUF = 2 * AH + 2 * BH;                         // one K tile: [HA0 | HA1 | HB0 | HB1]
+    constexpr int NA = WM, NB = WN / 2;                          // global_load_lds per thread per half-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,60 +62,72 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
     const int NT = ntm * ntn, G = gridDim.x;
     const bool vec = ep.vec_ok(coff, roff);
 
-    // staging: wave w, instruction i covers LDS rows (w*2+i)*8 .. +7 of a half-tile
-    const int sr0 = (w * 2) * 8 + (l >> 3), sr1 = sr0 + 8;
-    const int sc[2] = {((l & 7) ^ ((sr0 >> 1) & 7)) * 8, ((l & 7) ^ ((sr1 >> 1) & 7)) * 8};
-    char* const swave = smem + w * 2048;
+    // staging: wave w, instruction i covers LDS rows (i*8 + w)*8 .. +7 of a half-tile; the swizzle term
+    // (row>>1)&7 = (w&1)*4 + (l>>4) does not depend on i
+    const int srow = w * 8 + (l >> 3);                           // + i*64
+    const int sc = ((l & 7) ^ (((w & 1) << 2) + (l >> 4))) * 8;  // swizzled SOURCE chunk (elements)
+    char* const swave = smem + w * 1024;
 
-    const int wr = w >> 2, wc = w & 3, g = l >> 4, lr = l & 15;
+    const int wr = w / WN, wc = w % WN, g = l >> 4, lr = l & 15;
     // fragment addresses: row*128 + ((ks*4+g) ^ ((row>>1)&7))*16; (row>>1)&7 == (lr>>1)&7 for every tile of this lane
     const int swz = (lr >> 1) & 7;
     const int aoff0 = (wr * 64 + lr) * 128 + ((g ^ swz) << 4), aoff1 = aoff0 ^ 64;
-    const int boff0 = 2 * G2_HALF + (wc * 32 + lr) * 128 + ((g ^ swz) << 4), boff1 = boff0 ^ 64;
+    const int boff0 = 2 * AH + (wc * 32 + lr) * 128 + ((g ^ swz) << 4), boff1 = boff0 ^ 64;
 
-    const bf16* wrow[4];
+    const bf16* wrow[2 * NB];
     int m0 = 0, n0 = 0;
     // persistent tile loop: round `base` handles tiles [base, base+G); inside a round block b takes the
     // XCD-grouped position, and consecutive tile indices walk 4 tile rows x all tile columns, so the 32
     // tiles resident on one XCD share 4 A panels and 8 W panels in its L2.
-    auto setup = [&](int base) -> bool {
+    auto setup = [&](int base) __attribute__((always_inline)) -> bool {
         const int nr = min(G, NT - base);
         if ((int)blockIdx.x >= nr) return false;
         const int t = base + xcd_remap(blockIdx.x, nr);
         const int per = 4 * ntn, mg = t / per, rem = t - mg * per;
         const int gm = min(4, ntm - mg * 4);
-        m0 = (mg * 4 + rem % gm) * 256; n0 = (rem / gm) * 256;
+        m0 = (mg * 4 + rem % gm) * BM; n0 = (rem / gm) * BN;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = i ? sr1 : sr0;
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                al.init(h * 2 + i, m0 + (r >> 6) * 128 + h * 64 + (r & 63));
+            for (int i = 0; i < NA; ++i) {
+                const int r = i * 64 + srow;                     // LDS row of the half-tile -> (wave row r>>6, row r&63)
+                al.init(h * NA + i, m0 + (r >> 6) * 128 + h * 64 + (r & 63));
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int r = i * 64 + srow;
                 const int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
-                wrow[h * 2 + i] = Wb + (long)(n < N ? n : N - 1) * ldb;
+                wrow[h * NB + i] = Wb + (long)(n < N ? n : N - 1) * ldb;
             }
         }
         return true;
     };
-    auto stage_A = [&](int h, int T) {
+    auto stage_A = [&](auto hc, int T) __attribute__((always_inline)) {
+        constexpr int h = decltype(hc)::value;
         const int k0 = (T < nk ? T : nk - 1) * G2_BK;
-        char* d = swave + (T & 1) * G2_BUF + h * G2_HALF;
+        char* d = swave + (T & 1) * BUF + h * AH;
         al.set_ktile(k0);
-        glds16(al.ptr(h * 2 + 0, k0 + sc[0]), d);
-        glds16(al.ptr(h * 2 + 1, k0 + sc[1]), d + 1024);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(al.ptr(h * NA + i, k0 + sc), d + i * 8192);
     };
-    auto stage_B = [&](int h, int T) {
+    auto stage_B = [&](auto hc, int T) __attribute__((always_inline)) {
+        constexpr int h = decltype(hc)::value;
         const int k0 = (T < nk ? T : nk - 1) * G2_BK;
-        char* d = swave + (T & 1) * G2_BUF + 2 * G2_HALF + h * G2_HALF;
-        glds16(wrow[h * 2 + 0] + k0 + sc[0], d);
-        glds16(wrow[h * 2 + 1] + k0 + sc[1], d + 1024);
+        char* d = swave + (T & 1) * BUF + 2 * AH + h * BH;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) glds16(wrow[h * NB + i] + k0 + sc, d + i * 8192);
     };
     // tile 0 complete + the first two halves of tile 1, in stream order
-    auto prologue = [&]() { stage_A(0, 0); stage_B(0, 0); stage_B(1, 0); stage_A(1, 0); stage_A(0, 1); stage_B(0, 1); };
+    constexpr std::integral_constant<int, 0> H0{}; constexpr std::integral_constant<int, 1> H1{};
+    auto prologue = [&]() __attribute__((always_inline)) { stage_A(H0, 0); stage_B(H0, 0); stage_B(H1, 0); stage_A(H1, 0); stage_A(H0, 1); stage_B(H0, 1); };
 
     f32x4 acc[8][4];
     bf16x8 a[4][2], b0[2][2], b1[2][2];
 
+    // counted wait: the four half-tiles issued after the one needed next = 2 A + 2 W halves
+#define G2_WAIT()                                                                                           \
+    if constexpr (2 * NA + 2 * NB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                   \
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     // operands swapped (W fragment first): D rows = n, D cols = m, so a lane holds 4 CONSECUTIVE columns
     // n = g*4 .. +3 of row m = lr -> one 16-byte store per MFMA tile in the epilogue
 #define G2_MFMA_SECTION(MH, BF, NH)                                                                         \
@@ -132,113 +151,53 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        G2_WAIT()
         g2_barrier();
-        if constexpr (SCHED == 1) {
+        if (wr >= WM / 2) g2_barrier();                   // second wave group runs one barrier behind
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* buf = smem + (kt & 1) * BUF;
+            // ---- phase 1: quadrant (0,0): fragments of HB0 and HA0; stage HB1(kt+1)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                b0[nt][0] = *(const bf16x8*)(smem + boff0 + nt * 2048);
-                b0[nt][1] = *(const bf16x8*)(smem + boff1 + nt * 2048);
+                b0[nt][0] = *(const bf16x8*)(buf + boff0 + nt * 2048);
+                b0[nt][1] = *(const bf16x8*)(buf + boff1 + nt * 2048);
             }
-        }
-        if (STAGGER && wr == 1) g2_barrier();
-
-        if constexpr (SCHED == 1) {
-            // Variant: the 4 HB0 fragment reads move from phase 1 (12 ds_reads) to phase 4 of the PREVIOUS
-            // K tile (0 reads) into the register set B1 just vacated -> 8/4/8/4 reads per phase; the two
-            // B register sets swap roles every K tile.  Counted waits: P1 vmcnt(8), P2 vmcnt(8),
-            // P3 vmcnt(6) (retires HB0(kt+1), issued 3 half-tiles earlier, and HA0(kt+1) before it), P4 none.
-#define G2_TILE(KT, BX, BY)                                                                                 \
-            {                                                                                               \
-                const char* buf = smem + ((KT) & 1) * G2_BUF;                                               \
-                const char* nbuf = smem + (((KT) + 1) & 1) * G2_BUF;                                        \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                          \
-                    a[mt][0] = *(const bf16x8*)(buf + aoff0 + mt * 2048);                                   \
-                    a[mt][1] = *(const bf16x8*)(buf + aoff1 + mt * 2048);                                   \
-                }                                                                                           \
-                stage_B(1, (KT) + 1);                                                                       \
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
-                __builtin_amdgcn_sched_barrier(0);                                                          \
-                G2_MFMA_SECTION(0, BX, 0)                                                                   \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                          \
-                    BY[nt][0] = *(const bf16x8*)(buf + G2_HALF + boff0 + nt * 2048);                        \
-                    BY[nt][1] = *(const bf16x8*)(buf + G2_HALF + boff1 + nt * 2048);                        \
-                }                                                                                           \
-                stage_A(1, (KT) + 1);                                                                       \
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                            \
-                __builtin_amdgcn_sched_barrier(0);                                                          \
-                G2_MFMA_SECTION(0, BY, 1)                                                                   \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                          \
-                    a[mt][0] = *(const bf16x8*)(buf + G2_HALF + aoff0 + mt * 2048);                         \
-                    a[mt][1] = *(const bf16x8*)(buf + G2_HALF + aoff1 + mt * 2048);                         \
-                }                                                                                           \
-                stage_A(0, (KT) + 2);                                                                       \
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                            \
-                __builtin_amdgcn_sched_barrier(0);                                                          \
-                G2_MFMA_SECTION(1, BY, 1)                                                                   \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                          \
-                    BY[nt][0] = *(const bf16x8*)(nbuf + boff0 + nt * 2048);                                 \
-                    BY[nt][1] = *(const bf16x8*)(nbuf + boff1 + nt * 2048);                                 \
-                }                                                                                           \
-                stage_B(0, (KT) + 2);                                                                       \
-                __builtin_amdgcn_sched_barrier(0);                                                          \
-                G2_MFMA_SECTION(1, BX, 0)                                                                   \
-            }
-            for (int kt = 0; kt < nk; kt += 2) {
-                G2_TILE(kt, b0, b1)
-                if (kt + 1 < nk) G2_TILE(kt + 1, b1, b0)
-            }
-#undef G2_TILE
-        } else
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* buf = smem + (kt & 1) * G2_BUF;
-            // ---- phase 1: quadrant (0,0): fragments of HB0 and HA0; stage HB1(kt+1)
-            if (!(ABL & 2) || kt == 0) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    b0[nt][0] = *(const bf16x8*)(buf + boff0 + nt * 2048);
-                    b0[nt][1] = *(const bf16x8*)(buf + boff1 + nt * 2048);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    a[mt][0] = *(const bf16x8*)(buf + aoff0 + mt * 2048);
-                    a[mt][1] = *(const bf16x8*)(buf + aoff1 + mt * 2048);
-                }
+            for (int mt = 0; mt < 4; ++mt) {
+                a[mt][0] = *(const bf16x8*)(buf + aoff0 + mt * 2048);
+                a[mt][1] = *(const bf16x8*)(buf + aoff1 + mt * 2048);
             }
-            if (!(ABL & 1)) stage_B(1, kt + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            stage_B(H1, kt + 1);
+            G2_WAIT()
             __builtin_amdgcn_sched_barrier(0);
             G2_MFMA_SECTION(0, b0, 0)
             // ---- phase 2: quadrant (0,1): fragments of HB1; stage HA1(kt+1)
-            if (!(ABL & 2) || kt == 0) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    b1[nt][0] = *(const bf16x8*)(buf + G2_HALF + boff0 + nt * 2048);
-                    b1[nt][1] = *(const bf16x8*)(buf + G2_HALF + boff1 + nt * 2048);
-                }
+            for (int nt = 0; nt < 2; ++nt) {
+                b1[nt][0] = *(const bf16x8*)(buf + BH + boff0 + nt * 2048);
+                b1[nt][1] = *(const bf16x8*)(buf + BH + boff1 + nt * 2048);
             }
-            if (!(ABL & 1)) stage_A(1, kt + 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            stage_A(H1, kt + 1);
+            G2_WAIT()
             __builtin_amdgcn_sched_barrier(0);
             G2_MFMA_SECTION(0, b1, 1)
             // ---- phase 3: quadrant (1,1): fragments of HA1; stage HA0(kt+2)
-            if (!(ABL & 2) || kt == 0) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    a[mt][0] = *(const bf16x8*)(buf + G2_HALF + aoff0 + mt * 2048);
-                    a[mt][1] = *(const bf16x8*)(buf + G2_HALF + aoff1 + mt * 2048);
-                }
+            for (int mt = 0; mt < 4; ++mt) {
+                a[mt][0] = *(const bf16x8*)(buf + AH + aoff0 + mt * 2048);
+                a[mt][1] = *(const bf16x8*)(buf + AH + aoff1 + mt * 2048);
             }
-            if (!(ABL & 1)) stage_A(0, kt + 2);
+            stage_A(H0, kt + 2);
             __builtin_amdgcn_sched_barrier(0);
             G2_MFMA_SECTION(1, b1, 1)
             // ---- phase 4: quadrant (1,0): B0 still in registers; stage HB0(kt+2)
-            if (!(ABL & 1)) stage_B(0, kt + 2);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            stage_B(H0, kt + 2);
+            G2_WAIT()
             __builtin_amdgcn_sched_barrier(0);
             G2_MFMA_SECTION(1, b0, 0)
         }
-        if (STAGGER && wr == 0) g2_barrier();
+        if (wr < WM / 2) g2_barrier();
         // every wave is past its last ds_read: the next tile's first loads go out before this tile's
         // stores (same vmcnt counter, but loads return in order among themselves and the clamped tail
         // stages of this tile were issued earlier by the same wave to the same LDS bytes)
@@ -252,63 +211,47 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
             for (int nt = 0; nt < 4; ++nt) ep.store4(coff, roff, em0 + mt * 16, en0 + nt * 16, acc[mt][nt], vec);
     }
 #undef G2_MFMA_SECTION
+#undef G2_WAIT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // clamped tail stages must not outlive the block's LDS
 }
 
-int g_gemm256 = 1;          // pg_set_option("gemm256", 0/1/2): 0 off, 1 staggered, 2 lock-step (debug)
+int g_gemm256 = 1;          // pg_set_option("gemm256", 0/1): 0 = 128x128 kernel everywhere
 
-template <class AL>
+template <class AL, int WM, int WN>
 static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long strideA, long strideB, long strideA2, long strideB2,
                       const Epi<bf16>& ep, int M, int N, int K, int batch, int batch2) {
-    const int ntm = (M + 255) / 256, ntn = (N + 255) / 256;
+    constexpr int BM = WM * 128, BN = WN * 64, LDS = 2 * (2 * WM * 64 * 128 + 2 * WN * 32 * 128);
+    const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int per_batch = 256 / (batch * batch2) > 8 ? 256 / (batch * batch2) : 8;   // blocks per (batch) slice: one per CU overall
     dim3 grid(ntm * ntn < per_batch ? ntm * ntn : per_batch, batch, batch2), block(512);
-    if (g_gemm256 >= 11 && g_gemm256 <= 13) {
-        if constexpr (std::is_same<AL, PlainLoaderB<bf16>>::value) {
-            void (*kfn)(AL, const bf16*, long, long, long, long, long, Epi<bf16>, int, int, int, int, int) =
-                g_gemm256 == 11 ? gemm256_kernel<AL, Epi<bf16>, true, 1> : g_gemm256 == 12 ? gemm256_kernel<AL, Epi<bf16>, true, 2> : gemm256_kernel<AL, Epi<bf16>, true, 3>;
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
-            hipLaunchKernelGGL(kfn, grid, block, G2_LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
-        }
-        return;
-    }
-    if (g_gemm256 == 3) {
-        auto kfn = gemm256_kernel<AL, Epi<bf16>, true, 0, 1>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS); attr = true; }
-        hipLaunchKernelGGL(kfn, grid, block, G2_LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
-        return;
-    }
-    if (g_gemm256 == 2) {
-        auto kfn = gemm256_kernel<AL, Epi<bf16>, false>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS); attr = true; }
-        hipLaunchKernelGGL(kfn, grid, block, G2_LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
-    } else {
-        auto kfn = gemm256_kernel<AL, Epi<bf16>, true>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS); attr = true; }
-        hipLaunchKernelGGL(kfn, grid, block, G2_LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
-    }
+    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
 }
 
-// Takes the shapes the 256^2 tile fills well; everything else stays on the 128^2 kernel.
+// Takes the shapes the big tiles fill well; everything else stays on the 128^2 kernel.
 bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e, int M, int N, int K,
                  int batch, int batch2, long strideB2) {
     if (!g_gemm256 || K % G2_BK || K < 2 * G2_BK) return false;
-    const int ntm = (M + 255) / 256, ntn = (N + 255) / 256;
+    // (a 4x2-wave 512x128 instantiation for the Cout = 128 convolutions was measured: 470-560 TFLOP/s against
+    // 640-690 for the 128x128 kernel -- K = 9*Cin is only 18-36 K tiles, so the fill / drain of one persistent
+    // block per CU and the 8-slot im2col address state outweigh the deeper pipeline; not instantiated)
+    const int BM = 256, BN = 256;
+    const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     // padding waste of the last tile row / column, and enough tiles to fill the chip
-    if ((long)ntm * 256 * ntn * 256 > (long)M * N * 5 / 4) return false;
+    if ((long)ntm * BM * ntn * BN > (long)M * N * 5 / 4) return false;
     if ((long)ntm * ntn * batch * batch2 < 200) return false;
     Epi<bf16> ep{e, M, N};
     if (a.kind == 0) {
         PlainLoaderB<bf16> al; al.A = (const bf16*)a.ptr; al.lda = a.lda; al.M = M;
-        launch256(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
-    } else {
-        ConvLoaderB<bf16> al; al.X = (const bf16*)a.ptr; al.zeros = (const bf16*)a.zeros;
-        al.Hi = a.Hi; al.Wi = a.Wi; al.Cin = a.Cin; al.up = a.up; al.stride2 = (a.kind == 2);
-        al.Ho = al.stride2 ? a.Hi / 2 : (a.Hi << a.up); al.Wo = al.stride2 ? a.Wi / 2 : (a.Wi << a.up); al.M = M;
-        launch256(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+        launch256<PlainLoaderB<bf16>, 2, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+        return true;
     }
+    const int Ho = a.kind == 2 ? a.Hi / 2 : (a.Hi << a.up), Wo = a.kind == 2 ? a.Wi / 2 : (a.Wi << a.up);
+    const long in_elems = ((long)M / ((long)Ho * Wo)) * a.Hi * a.Wi * a.Cin;
+    if (in_elems >= (1L << 31)) return false;             // the slim loader keeps 32-bit element offsets
+    ConvLoaderS<4> al; al.setup(a, M);
+    launch256<ConvLoaderS<4>, 2, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
     return true;
 }

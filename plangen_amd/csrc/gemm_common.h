@@ -7,7 +7,7 @@
 template <typename T>
 struct PlainLoader {
     const T* A; long lda; int M;
-    const T* rowp[4];
+    const T* rowp[8];
     __device__ __forceinline__ void init(int i, int m) { rowp[i] = A + (long)(m < M ? m : M - 1) * lda; }
     __device__ __forceinline__ void set_ktile(int) {}
     __device__ __forceinline__ const T* ptr(int i, int k) const { return rowp[i] + k; }
@@ -65,6 +65,47 @@ struct ConvLoader {
         int sy, sx;
         if (!src_yx(y, x, ddy, ddx, sy, sx)) return 0.f;
         return ET<T>::ld(X + (((long)b * Hi + sy) * Wi + sx) * Cin + ci);
+    }
+};
+
+// Same addressing as ConvLoader with NS staging slots in 3 registers each (32-bit element offsets: image
+// base, packed output (y, x), source pixel of the current tap or -1 for the zero halo) -- the big-tile
+// kernels spend their registers on accumulators.  bf16 only; input must hold < 2^31 elements.
+template <int NS>
+struct ConvLoaderS {
+    const bf16* X; const bf16* zeros; int Hi, Wi, Cin, up, stride2, Ho, Wo, M;
+    int ibase[NS], yx[NS], cur[NS];
+    int ci0, cur_tap;
+    void setup(const GemmA& a, int M_) {
+        X = (const bf16*)a.ptr; zeros = (const bf16*)a.zeros; Hi = a.Hi; Wi = a.Wi; Cin = a.Cin; up = a.up; stride2 = (a.kind == 2);
+        Ho = stride2 ? a.Hi / 2 : (a.Hi << a.up); Wo = stride2 ? a.Wi / 2 : (a.Wi << a.up); M = M_;
+    }
+    __device__ __forceinline__ void A_offset(long off) { X += off; }
+    __device__ __forceinline__ void init(int i, int m) {
+        if (m >= M) m = M - 1;
+        const int x = m % Wo, t = m / Wo, y = t % Ho, b = t / Ho;
+        ibase[i] = b * Hi * Wi * Cin; yx[i] = (y << 16) | x;
+        cur_tap = -1;
+    }
+    __device__ __forceinline__ void set_ktile(int k0) {
+        const int lc = 31 - __builtin_clz(Cin);
+        const int tap = k0 >> lc; ci0 = k0 & (Cin - 1);
+        if (tap != cur_tap) {
+            cur_tap = tap;
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int y = yx[i] >> 16, x = yx[i] & 0xffff;
+                int sy, sx; bool ok;
+                if (stride2) { sy = 2 * y + dy; sx = 2 * x + dx; ok = sy < Hi && sx < Wi; }
+                else { const int oy = y + dy - 1, ox = x + dx - 1; sy = oy >> up; sx = ox >> up; ok = oy >= 0 && oy < Ho && ox >= 0 && ox < Wo; }
+                cur[i] = ok ? ibase[i] + (sy * Wi + sx) * Cin : -1;
+            }
+        }
+    }
+    __device__ __forceinline__ const bf16* ptr(int i, int k) const {
+        const int koff = k & 63;
+        return cur[i] >= 0 ? X + (cur[i] + ci0 + koff) : zeros + koff;
     }
 };
 
