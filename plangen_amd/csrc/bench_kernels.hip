@@ -2,6 +2,7 @@
 // weights rotated through > 256 MiB so the Infinity Cache cannot hold them).  Tuning aid only.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include "../../include/plangen_hip.h"
 #include "kernels.h"
@@ -115,6 +116,7 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     if (conv) { ga.kind = 1; ga.Hi = Hi; ga.Wi = Wi; ga.Cin = Cin; ga.up = up; ga.zeros = zeros; }
     GemmEpi e; e.out = o0; e.out_f32 = 1; e.ldc = N;
     const int saved = g_gemm256;
+    if (getenv("PG_CONV_HALO")) g_conv_halo = atoi(getenv("PG_CONV_HALO"));
     hipDeviceSynchronize();
     if (verify) {
         hipMalloc((void**)&o1, (long)M * N * 4);

@@ -1,0 +1,200 @@
+// 3x3 / pad 1 / stride 1 convolution, Cin = Cout = 128, NHWC bf16 in, fp32 or bf16 out, for gfx950:
+// the VQ-16 decoder's 384^2 and 192^2 ResBlock convolutions (11 of its 13 Cout=128 convolutions, half of the
+// decoder's time on the im2col-per-K-tile GEMM kernel).
+//
+// Direct convolution with an LDS-resident INPUT HALO TILE: a block owns 8 x 32 output pixels x all 128 output
+// channels.  The (8+2) x (32+2) x 128-channel input patch (85 KiB) is brought into LDS ONCE with
+// global_load_lds (out-of-image pixels come from a zero page) and serves all 9 taps x 128 channels = 18 K
+// tiles of 64: the A operand is never re-fetched per tap, only the weights stream (16 KiB per K tile, a
+// 4-slot LDS ring three tiles ahead, counted vmcnt, one barrier per K tile).
+//
+//   waves: 8 = 4 (pixel rows pairs) x 2 (64 output channels); a wave owns 2 rows x 32 px = 4 MFMA m-tiles of
+//          16 consecutive pixels, and 4 n-tiles: acc 4x4 f32x4, 32 MFMAs (16x16x32 bf16) per K tile.
+//   halo LDS layout: [halo pixel hp][16 chunks of 16 B], chunk position XOR (hp & 15) -- applied through the
+//          SOURCE address of the LDS-DMA (the DMA writes lane-linear).  A fragment read of 16 consecutive
+//          pixels x 4 k-groups then touches 16 distinct 16-byte slots per lane group (pixel stride 256 B would
+//          otherwise be a 16-way conflict).  The four k-steps of a tap are address ^ {0, 64, 128, 192}.
+//   weights: [Cout][tap][Cin] (K = tap*128 + ci, the engine's conv layout); LDS rows of 128 B with the
+//          (row>>1)&7 XOR swizzle of the GEMM kernels.
+//   operands swapped in the MFMA (D = W . A^T): a lane holds 4 consecutive output channels of one pixel ->
+//          16-byte epilogue accesses (bias, fp32 residual, store) through the shared Epi.
+//   persistent: one block per CU walks tiles in image-row order (neighbouring tiles share halo rows in L2).
+#include "gemm_common.h"
+
+#define CH_TH 8
+#define CH_TW 32
+#define CH_HW (CH_TW + 2)                       // halo width 34
+#define CH_HP ((CH_TH + 2) * CH_HW)             // 340 halo pixels
+#define CH_HALO_BYTES (88 * 1024)               // 88 wave-instructions x 1 KiB (>= 340 x 256 B)
+#define CH_WSLOT 16384                          // one K tile of weights: 128 rows x 128 B
+#define CH_LDS (CH_HALO_BYTES + 4 * CH_WSLOT)
+#define CH_NKT 18                               // 9 taps x (128 / 64)
+
+template <class EP, bool STAG>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt,
+                                                          const bf16* __restrict__ zeros, EP ep, int B, int H, int Wd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wlds = smem + CH_HALO_BYTES;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, g = l >> 4, lr = l & 15;
+    const int tiles_x = Wd / CH_TW, tiles_y = H / CH_TH, tiles_img = tiles_x * tiles_y;
+    const int NT = tiles_img * B, G = gridDim.x;
+    const bool vec = ep.vec_ok(0, 0);
+
+    // weight staging: wave w, instruction i covers LDS rows (i*8 + w)*8 .. +7 (row = output channel)
+    const int wsrow = w * 8 + (l >> 3);
+    const int wsc = ((l & 7) ^ (((w & 1) << 2) + (l >> 4))) * 8;               // swizzled source chunk (elements)
+    const bf16* wsrc0 = Wt + (long)wsrow * (9 * 128) + wsc;
+    const bf16* wsrc1 = wsrc0 + (long)64 * (9 * 128);
+    auto stage_w = [&](int t) __attribute__((always_inline)) {
+        const int tt = t < CH_NKT ? t : CH_NKT - 1;                            // clamped tail: keeps the counts exact
+        char* d = wlds + (t & 3) * CH_WSLOT + w * 1024;
+        glds16(wsrc0 + tt * 64, d);
+        glds16(wsrc1 + tt * 64, d + 8192);
+    };
+    // B (weight) fragment addresses inside a slot
+    const int swz = (lr >> 1) & 7;
+    const int boff0 = (wc * 64 + lr) * 128 + ((g ^ swz) << 4), boff1 = boff0 ^ 64;
+    // A fragment: halo pixel of (m-tile mt, tap) = hp0 + (mt>>1)*34 + (mt&1)*16 + dy*34 + dx
+    const int hp0 = (wr * 2) * CH_HW + lr;
+
+    f32x4 acc[4][4];
+    bf16x8 af[4][2], bfr[4][2];
+
+    int b = 0, y0 = 0, x0 = 0;
+    // halo fill (11 LDS-DMA instructions per wave, 4 halo pixels x 16 chunks each) + the first three weight tiles
+    auto fill = [&](int tix) __attribute__((always_inline)) {
+        b = tix / tiles_img;
+        const int r = tix - b * tiles_img;
+        y0 = (r / tiles_x) * CH_TH; x0 = (r % tiles_x) * CH_TW;
+        const bf16* img = X + (long)b * H * Wd * 128;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int q = j * 8 + w;                                           // wave-instruction index, 1 KiB each
+            int hp = q * 4 + (l >> 4);
+            const int pos = l & 15;
+            const bool inr = hp < CH_HP;
+            hp = inr ? hp : CH_HP - 1;
+            const int hy = hp / CH_HW, hx = hp - hy * CH_HW;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = inr && y >= 0 && y < H && x >= 0 && x < Wd;
+            const int sch = pos ^ (hp & 15);
+            const bf16* src = ok ? img + ((long)y * Wd + x) * 128 + sch * 8 : zeros + sch * 8;
+            glds16(src, halo + q * 1024);
+        }
+        stage_w(0); stage_w(1);
+        if (!STAG) stage_w(2);
+    };
+    int tix = blockIdx.x;
+    if (tix < NT) fill(tix);
+    while (tix < NT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        if constexpr (STAG) {
+            // staggered wave groups (as in gemm256.hip): tile 0 + halo landed (W1 may still fly), then the
+            // second group runs one barrier behind, so one wave per SIMD reads LDS while the other runs MFMAs.
+            // Ring discipline under the stagger: W(t+2) is staged in phase t into the slot read in phase t-2;
+            // W(t+1) is retired by vmcnt(2) in phase t and read in phase t+1.
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (wr >= 2) asm volatile("s_barrier" ::: "memory");
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            int abase[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int hp = hp0 + ((mt >> 1) + dy) * CH_HW + (mt & 1) * 16 + dx;
+                abase[mt] = hp * 256 + (((hp & 15) ^ g) << 4);
+            }
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const int t = tap * 2 + kh;
+                if constexpr (!STAG) {
+                    // W tile t (and, for t == 0, the halo) has landed: the loads issued after it are tiles t+1, t+2
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                    stage_w(t + 3);                                            // slot of tile t-1: every wave is past its reads
+                }
+                const char* ws = wlds + (t & 3) * CH_WSLOT;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    bfr[nt][0] = *(const bf16x8*)(ws + boff0 + nt * 2048);
+                    bfr[nt][1] = *(const bf16x8*)(ws + boff1 + nt * 2048);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    af[mt][0] = *(const bf16x8*)(halo + (abase[mt] ^ ((kh * 2 + 0) << 6)));
+                    af[mt][1] = *(const bf16x8*)(halo + (abase[mt] ^ ((kh * 2 + 1) << 6)));
+                }
+                if constexpr (STAG) {
+                    stage_w(t + 2);
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_barrier" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STAG) asm volatile("s_barrier" ::: "memory");
+            }
+        }
+        if (STAG && wr < 2) asm volatile("s_barrier" ::: "memory");
+        // every wave must be done with the halo before the next tile's fill overwrites it; the fill (and the
+        // first weight tiles) then go out BEFORE this tile's stores so they fly during the epilogue
+        if (!STAG) asm volatile("s_barrier" ::: "memory");
+        const long mrow = ((long)b * H + y0 + wr * 2) * Wd + x0 + lr;
+        tix += G;
+        if (tix < NT) fill(tix);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const long m = mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) ep.store4(0, 0, (int)m, wc * 64 + nt * 16 + g * 4, acc[mt][nt], vec);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int g_conv_halo = 1;        // pg_set_option("conv_halo", 0/1)
+
+// Takes 3x3 / pad 1 / stride 1 convolutions with Cin = Cout = 128 on images whose sides are multiples of the
+// 8 x 32 tile; returns false otherwise (the implicit-GEMM kernels handle the rest).
+bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K) {
+    if (!g_conv_halo || a.kind != 1 || a.up != 0 || a.Cin != 128 || N != 128 || K != 9 * 128) return false;
+    if (a.Hi % CH_TH || a.Wi % CH_TW || a.strideA || e.strideC) return false;
+    const long px = (long)a.Hi * a.Wi;
+    if (M % px || (long)M >= (1L << 31) / 1) return false;
+    const int B = (int)(M / px);
+    const int tiles = B * (a.Hi / CH_TH) * (a.Wi / CH_TW);
+    if (tiles < 128) return false;
+    Epi<bf16> ep{e, M, N};
+    const dim3 grid(tiles < 256 ? tiles : 256), block(512);
+    if (g_conv_halo == 2) {
+        auto kfn = conv3x3_halo_kernel<Epi<bf16>, false>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS); attr = true; }
+        hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, a.Hi, a.Wi);
+    } else {
+        auto kfn = conv3x3_halo_kernel<Epi<bf16>, true>;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS); attr = true; }
+        hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, a.Hi, a.Wi);
+    }
+    return true;
+}

@@ -1340,6 +1340,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
     if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
     if (!strcmp(key, "gemm256")) { g_gemm256 = (int)value; return PG_OK; }
+    if (!strcmp(key, "conv_halo")) { g_conv_halo = (int)value; return PG_OK; }
     if (!strcmp(key, "attn_waves")) { g_attn_waves = (int)value; h->drop_graphs(); return PG_OK; }
     if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; h->drop_graphs(); return PG_OK; }
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->drop_graphs(); return PG_OK; }

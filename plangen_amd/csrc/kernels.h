@@ -41,6 +41,9 @@ void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strid
 bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e, int M, int N, int K,
                  int batch, int batch2, long strideB2);
 extern int g_gemm256;
+// direct 3x3 convolution with an LDS-resident input halo tile (conv_halo.hip), Cin = Cout = 128
+bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K);
+extern int g_conv_halo;
 extern int g_attn_waves;
 
 // Skinny weight-streaming GEMM (decode): x [M,K] bf16 (M <= 128 per launch block-row),
