@@ -19,6 +19,10 @@
 //   operands swapped in the MFMA (D = W . A^T): a lane holds 4 consecutive output channels of one pixel ->
 //          16-byte epilogue accesses (bias, fp32 residual, store) through the shared Epi.
 //   persistent: one block per CU walks tiles in image-row order (neighbouring tiles share halo rows in L2).
+//   UP: the nearest-2x upsample in front of the convolution (vq_model.py:417-427) folded into the addressing:
+//          H x W is the OUTPUT size, the input is H/2 x W/2, the halo patch is the 6 x 18 SOURCE pixels an
+//          8 x 32 output tile touches, and output pixel (py, px), tap (dy, dx) reads source halo pixel
+//          (((py+dy-1)>>1)+1, ((px+dx-1)>>1)+1); zero padding of the upsampled image == zero padding of the source.
 #include "gemm_common.h"
 
 #define CH_TH 8
@@ -30,7 +34,7 @@
 #define CH_LDS (CH_HALO_BYTES + 4 * CH_WSLOT)
 #define CH_NKT 18                               // 9 taps x (128 / 64)
 
-template <class EP, bool STAG>
+template <class EP, bool STAG, bool UP>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt,
                                                           const bf16* __restrict__ zeros, EP ep, int B, int H, int Wd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,19 +73,22 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
         b = tix / tiles_img;
         const int r = tix - b * tiles_img;
         y0 = (r / tiles_x) * CH_TH; x0 = (r % tiles_x) * CH_TW;
-        const bf16* img = X + (long)b * H * Wd * 128;
+        constexpr int HWD = UP ? CH_TW / 2 + 2 : CH_HW, NHP = UP ? (CH_TH / 2 + 2) * HWD : CH_HP, NJ = UP ? 4 : 11;
+        const int Hs = UP ? H / 2 : H, Ws = UP ? Wd / 2 : Wd;                    // source image
+        const int sy0 = (UP ? y0 / 2 : y0) - 1, sx0 = (UP ? x0 / 2 : x0) - 1;      // source coords of halo pixel (0, 0)
+        const bf16* img = X + (long)b * Hs * Ws * 128;
 #pragma unroll
-        for (int j = 0; j < 11; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int q = j * 8 + w;                                           // wave-instruction index, 1 KiB each
             int hp = q * 4 + (l >> 4);
             const int pos = l & 15;
-            const bool inr = hp < CH_HP;
-            hp = inr ? hp : CH_HP - 1;
-            const int hy = hp / CH_HW, hx = hp - hy * CH_HW;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool ok = inr && y >= 0 && y < H && x >= 0 && x < Wd;
+            const bool inr = hp < NHP;
+            hp = inr ? hp : NHP - 1;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = sy0 + hy, x = sx0 + hx;
+            const bool ok = inr && y >= 0 && y < Hs && x >= 0 && x < Ws;
             const int sch = pos ^ (hp & 15);
-            const bf16* src = ok ? img + ((long)y * Wd + x) * 128 + sch * 8 : zeros + sch * 8;
+            const bf16* src = ok ? img + ((long)y * Ws + x) * 128 + sch * 8 : zeros + sch * 8;
             glds16(src, halo + q * 1024);
         }
         stage_w(0); stage_w(1);
@@ -110,7 +117,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
             int abase[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int hp = hp0 + ((mt >> 1) + dy) * CH_HW + (mt & 1) * 16 + dx;
+                int hp;
+                if constexpr (UP) hp = (((wr * 2 + (mt >> 1) + dy - 1) >> 1) + 1) * (CH_TW / 2 + 2) + (((mt & 1) * 16 + lr + dx - 1) >> 1) + 1;
+                else hp = hp0 + ((mt >> 1) + dy) * CH_HW + (mt & 1) * 16 + dx;
                 abase[mt] = hp * 256 + (((hp & 15) ^ g) << 4);
             }
 #pragma unroll
@@ -176,25 +185,25 @@ int g_conv_halo = 1;        // pg_set_option("conv_halo", 0/1)
 // Takes 3x3 / pad 1 / stride 1 convolutions with Cin = Cout = 128 on images whose sides are multiples of the
 // 8 x 32 tile; returns false otherwise (the implicit-GEMM kernels handle the rest).
 bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K) {
-    if (!g_conv_halo || a.kind != 1 || a.up != 0 || a.Cin != 128 || N != 128 || K != 9 * 128) return false;
-    if (a.Hi % CH_TH || a.Wi % CH_TW || a.strideA || e.strideC) return false;
-    const long px = (long)a.Hi * a.Wi;
-    if (M % px || (long)M >= (1L << 31) / 1) return false;
+    if (!g_conv_halo || a.kind != 1 || a.up > 1 || a.Cin != 128 || N != 128 || K != 9 * 128) return false;
+    const int H = a.Hi << a.up, Wd = a.Wi << a.up;                 // output size
+    if (H % CH_TH || Wd % CH_TW || a.strideA || e.strideC) return false;
+    const long px = (long)H * Wd;
+    if (M % px) return false;
     const int B = (int)(M / px);
-    const int tiles = B * (a.Hi / CH_TH) * (a.Wi / CH_TW);
+    const int tiles = B * (H / CH_TH) * (Wd / CH_TW);
     if (tiles < 128) return false;
     Epi<bf16> ep{e, M, N};
     const dim3 grid(tiles < 256 ? tiles : 256), block(512);
-    if (g_conv_halo == 2) {
-        auto kfn = conv3x3_halo_kernel<Epi<bf16>, false>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS); attr = true; }
-        hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, a.Hi, a.Wi);
-    } else {
-        auto kfn = conv3x3_halo_kernel<Epi<bf16>, true>;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS); attr = true; }
-        hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, a.Hi, a.Wi);
+#define CH_LAUNCH(STAG, UP)                                                                                                  \
+    {                                                                                                                         \
+        auto kfn = conv3x3_halo_kernel<Epi<bf16>, STAG, UP>;                                                                  \
+        static bool attr = false;                                                                                             \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS); attr = true; } \
+        hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, H, Wd);           \
     }
+    if (g_conv_halo == 2) { if (a.up) CH_LAUNCH(false, true) else CH_LAUNCH(false, false) }
+    else { if (a.up) CH_LAUNCH(true, true) else CH_LAUNCH(true, false) }
+#undef CH_LAUNCH
     return true;
 }

@@ -138,8 +138,9 @@ def test_conv3x3_256_tile_path(tiny_cfg, tiny_weights, up, stride2, res, B, Hs, 
     assert (o - ref).abs().max() < 2e-2 * ref.abs().max()
 
 
-@pytest.mark.parametrize("res,B,Hs,Ws", [(False, 4, 64, 128), (True, 3, 96, 160), (True, 1, 192, 192)])
-def test_conv3x3_halo_tile_path(tiny_cfg, tiny_weights, res, B, Hs, Ws):
+@pytest.mark.parametrize("res,B,Hs,Ws,up", [(False, 4, 64, 128, 0), (True, 3, 96, 160, 0), (True, 1, 192, 192, 0),
+                                            (False, 4, 32, 64, 1), (False, 2, 96, 96, 1)])
+def test_conv3x3_halo_tile_path(tiny_cfg, tiny_weights, res, B, Hs, Ws, up):
     """Cin = Cout = 128, sides multiple of the 8 x 32 tile, >= 128 tiles: the direct convolution with the
     LDS-resident input halo tile (conv_halo.hip).  Image borders (zero page), tile seams and the residual
     epilogue against torch; bit-for-bit against the implicit-GEMM kernel (same K order)."""
@@ -148,7 +149,7 @@ def test_conv3x3_halo_tile_path(tiny_cfg, tiny_weights, res, B, Hs, Ws):
     x = _round(torch.randn(B, 128, Hs, Ws, generator=g), "bf16")
     w = _round(torch.randn(128, 128, 3, 3, generator=g) / 34, "bf16")
     b = torch.randn(128, generator=g)
-    ref = F.conv2d(x, w, b, padding=1)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x, w, b, padding=1)
     r = None
     if res:
         r = _round(torch.randn(ref.shape, generator=g), "bf16")
@@ -156,9 +157,9 @@ def test_conv3x3_halo_tile_path(tiny_cfg, tiny_weights, res, B, Hs, Ws):
     xn = x.permute(0, 2, 3, 1).contiguous()
     rn = None if r is None else r.permute(0, 2, 3, 1).contiguous()
     e.set_option("conv_halo", 1)
-    out = e.op_conv3x3(xn, w, b, rn, 0, 0)
+    out = e.op_conv3x3(xn, w, b, rn, up, 0)
     e.set_option("conv_halo", 0)
-    out_gemm = e.op_conv3x3(xn, w, b, rn, 0, 0)
+    out_gemm = e.op_conv3x3(xn, w, b, rn, up, 0)
     e.set_option("conv_halo", 1)
     assert torch.equal(out, out_gemm)
     o = out.float().cpu().permute(0, 3, 1, 2)
