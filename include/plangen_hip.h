@@ -177,6 +177,20 @@ typedef struct pg_timing {
     float  vq_ms;              /* whole last pg_vq_decode */
 } pg_timing;
 int pg_get_timing(pg_handle h, pg_timing* out);
+/* Tuning / measurement switches (defaults in parentheses); none changes results except where noted:
+ *   time_attn (0)       per-launch HIP events around the decode-attention kernel (eager loop)
+ *   use_graph (1)       replay the decode step as a hipGraph
+ *   share_uncond (1)    prefill / store a batch-constant negative prompt once
+ *   flash_prefill (1)   MFMA flash attention for prefill (0: per-query streaming kernel)
+ *   fuse_rope (1)       RoPE + KV append inside the decode-attention kernel
+ *   lanes (1)           2: two row-range lanes on two streams
+ *   lpt_order (1)       longest rows first in the decode-attention launch
+ *   attn_variant, attn_waves (0; 4 pins 4-wave blocks)   decode-attention kernel variants
+ *   gemm256 (1)         256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)
+ *   conv_halo (1)       direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: off)
+ *   force_swiglu (1)    SwiGLU fused into the decode gate|up GEMM at every batch size
+ *   split_target_small / _mid / _big (128 / 256 / 128)   decode split-K block-count targets by row count
+ * Returns PG_ERR_ARG for an unknown key. */
 int pg_set_option(pg_handle h, const char* key, int64_t value);
 /* Bytes of device memory the handle owns (weights + KV + workspace). */
 int64_t pg_device_bytes(pg_handle h);
