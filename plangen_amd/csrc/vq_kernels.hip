@@ -248,30 +248,61 @@ template void launch_conv3x3_small<float>(hipStream_t, const float*, const float
 template void launch_conv3x3_small<bf16>(hipStream_t, const bf16*, const bf16*, const float*, void*, int, int, int, int, int, int);
 
 // ------------------------------------------------------------------------------- conv_in (Cin tiny)
-// Encoder conv_in 3 -> ch: NCHW input, NHWC T output; thread per (pixel, cout).
+// Encoder conv_in 3 -> ch (vq_model.py:60): NCHW input, NHWC T output.  One thread per OUTPUT CHANNEL
+// keeps its 27 weights in registers; a block walks a 64-pixel strip of one image row: the 3 x 3 x 66
+// input patch sits in LDS (zero padded), every pixel costs 9 broadcast LDS reads (the new window column),
+// 27 FMAs and one store that is contiguous across the channel lanes (512 B per pixel).
 template <typename T>
-__global__ void conv3x3_in_kernel(const void* __restrict__ x, int x_bf16, const float* __restrict__ w,
-                                  const float* __restrict__ bias, T* __restrict__ out, int H, int W, int Cin, int Cout) {
-    const int b = blockIdx.y;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)H * W * Cout) return;
-    const int co = (int)(i % Cout); const int p = (int)(i / Cout); const int y = p / W, xx = p % W;
-    float acc = bias[co];
-    for (int ci = 0; ci < Cin; ++ci)
-        for (int tap = 0; tap < 9; ++tap) {
-            const int sy = y + tap / 3 - 1, sx = xx + tap % 3 - 1;
-            if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
-            const long xi = (((long)b * Cin + ci) * H + sy) * W + sx;
-            const float v = x_bf16 ? ET<bf16>::ld((const bf16*)x + xi) : ((const float*)x)[xi];
-            acc = fmaf(v, w[((long)co * Cin + ci) * 9 + tap], acc);
+__global__ __launch_bounds__(128) void conv3x3_in_kernel(const void* __restrict__ x, int x_bf16, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, T* __restrict__ out, int H, int W, int Cout) {
+    __shared__ float patch[3][3][68];
+    const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * 64, tid = threadIdx.x;
+    for (int i = tid; i < 3 * 3 * 66; i += 128) {
+        const int ci = i / (3 * 66), r = (i / 66) % 3, c = i % 66;
+        const int sy = y + r - 1, sx = x0 + c - 1;
+        float v = 0.f;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            const long xi = (((long)b * 3 + ci) * H + sy) * W + sx;
+            v = x_bf16 ? ET<bf16>::ld((const bf16*)x + xi) : ((const float*)x)[xi];
         }
-    ET<T>::st(out + ((long)b * H * W + p) * Cout + co, acc);
+        patch[ci][r][c] = v;
+    }
+    __syncthreads();
+    for (int co = tid; co < Cout; co += 128) {
+        float wr[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) wr[k] = w[(long)co * 27 + k];              // [co][ci][tap]
+        const float bs = bias[co];
+        float win[3][3][3];                                                    // [ci][row][col]
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { win[ci][r][1] = patch[ci][r][0]; win[ci][r][2] = patch[ci][r][1]; }
+        const int npx = min(64, W - x0);
+        for (int p = 0; p < npx; ++p) {
+            float acc = bs;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    win[ci][r][0] = win[ci][r][1]; win[ci][r][1] = win[ci][r][2]; win[ci][r][2] = patch[ci][r][p + 2];
+                }
+            // same accumulation order as the reference loop: ci outer, tap = row*3 + col inner
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc = fmaf(win[ci][r][c], wr[ci * 9 + r * 3 + c], acc);
+            ET<T>::st(out + (((long)b * H + y) * W + x0 + p) * Cout + co, acc);
+        }
+    }
 }
 template <typename T>
 void launch_conv3x3_in(hipStream_t s, const void* x, int x_bf16, const float* w, const float* bias, T* out,
                        int B, int H, int W, int Cin, int Cout) {
-    const long n = (long)H * W * Cout;
-    hipLaunchKernelGGL(conv3x3_in_kernel<T>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, x, x_bf16, w, bias, out, H, W, Cin, Cout);
+    (void)Cin;                                                                 // == 3 (checked by the caller)
+    hipLaunchKernelGGL(conv3x3_in_kernel<T>, dim3((W + 63) / 64, H, B), dim3(128), 0, s, x, x_bf16, w, bias, out, H, W, Cout);
 }
 template void launch_conv3x3_in<float>(hipStream_t, const void*, int, const float*, const float*, float*, int, int, int, int, int);
 template void launch_conv3x3_in<bf16>(hipStream_t, const void*, int, const float*, const float*, bf16*, int, int, int, int, int);
