@@ -207,3 +207,93 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
 #undef CH_LAUNCH
     return true;
 }
+
+// ------------------------------------------------------------------------------- conv_out (128 -> 3)
+// Same halo tile, but Cout <= 4 is padded to ONE 16-wide MFMA n-tile whose weight fragments (36 k-steps x 4
+// registers, zero for the padding rows) live in registers for the whole persistent block: no weight traffic,
+// no barrier inside a tile.  Wave w owns output row w of the 8 x 32 tile (2 m-tiles).  NCHW output
+// (vq_model.py:213-214: the decoder's image), fp32 or bf16.
+__global__ __launch_bounds__(512) void conv3x3_out_halo_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt,
+                                                              const float* __restrict__ bias, const bf16* __restrict__ zeros,
+                                                              void* __restrict__ out, int out_bf16, int B, int H, int Wd, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = l >> 4, lr = l & 15;
+    const int tiles_x = Wd / CH_TW, tiles_y = H / CH_TH, tiles_img = tiles_x * tiles_y;
+    const int NT = tiles_img * B, G = gridDim.x;
+    // weight fragments: lane (lr = output channel, g) holds k = g*8 .. +7 of every 32-wide k-step
+    bf16x8 wf[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) {
+        wf[q] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (lr < Cout) wf[q] = *(const bf16x8*)(Wt + (long)lr * (9 * 128) + q * 32 + g * 8);
+    }
+    float bs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] = (g * 4 + j < Cout) ? bias[g * 4 + j] : 0.f;
+    const int hp0 = w * CH_HW + lr;
+    for (int tix = blockIdx.x; tix < NT; tix += G) {
+        const int b = tix / tiles_img, r = tix - b * tiles_img;
+        const int y0 = (r / tiles_x) * CH_TH, x0 = (r % tiles_x) * CH_TW;
+        const bf16* img = X + (long)b * H * Wd * 128;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const int q = j * 8 + w;
+            int hp = q * 4 + (l >> 4);
+            const int pos = l & 15;
+            const bool inr = hp < CH_HP;
+            hp = inr ? hp : CH_HP - 1;
+            const int hy = hp / CH_HW, hx = hp - hy * CH_HW;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = inr && y >= 0 && y < H && x >= 0 && x < Wd;
+            const int sch = pos ^ (hp & 15);
+            const bf16* src = ok ? img + ((long)y * Wd + x) * 128 + sch * 8 : zeros + sch * 8;
+            glds16(src, halo + q * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int hp = hp0 + dy * CH_HW + mt * 16 + dx;
+                const int ab = hp * 256 + (((hp & 15) ^ g) << 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x8 af = *(const bf16x8*)(halo + (ab ^ (q << 6)));
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap * 4 + q], af, acc[mt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);              // keep the fragment reads of later taps from piling up in registers
+        }
+        __syncthreads();                                   // halo free for the next tile
+        // D rows = output channel (g*4 + reg), D cols = pixel lr: only g == 0 lanes hold channels 0..3
+        if (g == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < Cout) {
+                        const long o = (((long)b * Cout + j) * H + y0 + w) * Wd + x0 + mt * 16 + lr;
+                        const float v = acc[mt][j] + bs[j];
+                        if (out_bf16) ET<bf16>::st((bf16*)out + o, v); else ((float*)out)[o] = v;
+                    }
+        }
+    }
+}
+
+bool conv_out_halo_try(hipStream_t s, const bf16* x, const bf16* w, const float* bias, const bf16* zeros, void* out, int out_bf16,
+                       int B, int H, int Wd, int Cin, int Cout) {
+    if (!g_conv_halo || Cin != 128 || Cout > 4 || H % CH_TH || Wd % CH_TW) return false;
+    const int tiles = B * (H / CH_TH) * (Wd / CH_TW);
+    if (tiles < 64) return false;
+    auto kfn = conv3x3_out_halo_kernel;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_HALO_BYTES); attr = true; }
+    hipLaunchKernelGGL(kfn, dim3(tiles < 256 ? tiles : 256), dim3(512), CH_HALO_BYTES, s, x, w, bias, zeros, out, out_bf16, B, H, Wd, Cout);
+    return true;
+}

@@ -1112,8 +1112,13 @@ int pg_engine::vq_decode(const int32_t* codes, void* img_out, int out_dtype, int
         }
     }
     gn<T>(s, dec.norm_out, (const float*)cur, (T*)t1, B, side * side, 1);
-    launch_conv3x3_small<T>(s, (const T*)t1, (const T*)dec.conv_out.w, dec.conv_out.b, img_out, out_dtype == PG_BF16, B, side, side,
-                            dec.conv_out.cin, 3);
+    bool co_done = false;
+    if constexpr (std::is_same<T, bf16>::value)
+        co_done = conv_out_halo_try(s, (const bf16*)t1, (const bf16*)dec.conv_out.w, dec.conv_out.b, (const bf16*)zeros, img_out,
+                                    out_dtype == PG_BF16, B, side, side, dec.conv_out.cin, 3);
+    if (!co_done)
+        launch_conv3x3_small<T>(s, (const T*)t1, (const T*)dec.conv_out.w, dec.conv_out.b, img_out, out_dtype == PG_BF16, B, side, side,
+                                dec.conv_out.cin, 3);
     HIPCHK(hipEventRecord(ev_v1, s));
     have_vq_t = true;
     HIPCHK(hipGetLastError());

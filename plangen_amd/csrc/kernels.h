@@ -44,6 +44,8 @@ extern int g_gemm256;
 // direct 3x3 convolution with an LDS-resident input halo tile (conv_halo.hip), Cin = Cout = 128
 bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K);
 extern int g_conv_halo;
+bool conv_out_halo_try(hipStream_t s, const bf16* x, const bf16* w, const float* bias, const bf16* zeros, void* out, int out_bf16,
+                       int B, int H, int Wd, int Cin, int Cout);
 extern int g_attn_waves;
 
 // Skinny weight-streaming GEMM (decode): x [M,K] bf16 (M <= 128 per launch block-row),
