@@ -31,15 +31,18 @@
 #define CH_HP ((CH_TH + 2) * CH_HW)             // 340 halo pixels
 #define CH_HALO_BYTES (88 * 1024)               // 88 wave-instructions x 1 KiB (>= 340 x 256 B)
 #define CH_WSLOT 16384                          // one K tile of weights: 128 rows x 128 B
-#define CH_LDS (CH_HALO_BYTES + 4 * CH_WSLOT)
+#define CH_RED (CH_HALO_BYTES + 4 * CH_WSLOT)       // 1 KiB: per-wave GroupNorm partials of the epilogue
+#define CH_LDS (CH_RED + 1024)
 #define CH_NKT 18                               // 9 taps x (128 / 64)
 
 template <class EP, bool STAG, bool UP>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt,
-                                                          const bf16* __restrict__ zeros, EP ep, int B, int H, int Wd) {
+                                                          const bf16* __restrict__ zeros, EP ep, int B, int H, int Wd,
+                                                          float* __restrict__ gn_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;
     char* const wlds = smem + CH_HALO_BYTES;
+    float* const red = (float*)(smem + CH_RED);
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 1, wc = w & 1, g = l >> 4, lr = l & 15;
@@ -168,13 +171,51 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
         // first weight tiles) then go out BEFORE this tile's stores so they fly during the epilogue
         if (!STAG) asm volatile("s_barrier" ::: "memory");
         const long mrow = ((long)b * H + y0 + wr * 2) * Wd + x0 + lr;
+        const int tile_id = tix;                                        // (image, tile) index of THIS tile
         tix += G;
         if (tix < NT) fill(tix);
+        if (gn_part && vec) {
+            // GroupNorm(32 groups of 4 channels) statistics of the values being stored: a lane's f32x4 is one
+            // group of one pixel.  Fixed-order reduction: 4 m-tiles in registers, 16 pixel lanes by shuffles,
+            // the 4 pixel-row waves through LDS -> one (sum, sum of squares) per (tile, group); the finalize
+            // kernel adds the tiles of an image in double.  Replaces the separate statistics pass.
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const long m = mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16;
+            for (int mt = 0; mt < 4; ++mt) {
+                const long m = mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) ep.store4(0, 0, (int)m, wc * 64 + nt * 16 + g * 4, acc[mt][nt], vec);
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int col = wc * 64 + nt * 16 + g * 4;
+                    const f32x4 v = ep.final4(0, (int)m, col, acc[mt][nt]);
+                    ep.put4(0, (int)m, col, v);
+                    s1[nt] += (v[0] + v[1]) + (v[2] + v[3]);
+                    s2[nt] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1[nt] += __shfl_xor(s1[nt], o, 64); s2[nt] += __shfl_xor(s2[nt], o, 64); }
+            if (lr == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) { red[(w * 16 + nt * 4 + g) * 2] = s1[nt]; red[(w * 16 + nt * 4 + g) * 2 + 1] = s2[nt]; }
+            }
+            __syncthreads();
+            if (tid < 32) {
+                const int gwc = tid >> 4, gi = tid & 15;                    // group = gwc*16 + gi
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) { a += red[((r4 * 2 + gwc) * 16 + gi) * 2]; q += red[((r4 * 2 + gwc) * 16 + gi) * 2 + 1]; }
+                gn_part[((long)tile_id * 32 + tid) * 2] = a; gn_part[((long)tile_id * 32 + tid) * 2 + 1] = q;
+            }
+            __syncthreads();                                            // red is rewritten by the next tile
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const long m = mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) ep.store4(0, 0, (int)m, wc * 64 + nt * 16 + g * 4, acc[mt][nt], vec);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -184,7 +225,7 @@ int g_conv_halo = 1;        // pg_set_option("conv_halo", 0/1)
 
 // Takes 3x3 / pad 1 / stride 1 convolutions with Cin = Cout = 128 on images whose sides are multiples of the
 // 8 x 32 tile; returns false otherwise (the implicit-GEMM kernels handle the rest).
-bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K) {
+bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K, float* gn_part, int* gn_nsplit) {
     if (!g_conv_halo || a.kind != 1 || a.up > 1 || a.Cin != 128 || N != 128 || K != 9 * 128) return false;
     const int H = a.Hi << a.up, Wd = a.Wi << a.up;                 // output size
     if (H % CH_TH || Wd % CH_TW || a.strideA || e.strideC) return false;
@@ -200,8 +241,10 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
         auto kfn = conv3x3_halo_kernel<Epi<bf16>, STAG, UP>;                                                                  \
         static bool attr = false;                                                                                             \
         if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS); attr = true; } \
-        hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, H, Wd);           \
+        hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, H, Wd, gn_part);  \
     }
+    if (gn_part && !(e.out_f32 && (e.ldc & 3) == 0)) gn_part = nullptr;
+    if (gn_nsplit) *gn_nsplit = gn_part ? (H / CH_TH) * (Wd / CH_TW) : 0;
     if (g_conv_halo == 2) { if (a.up) CH_LAUNCH(false, true) else CH_LAUNCH(false, false) }
     else { if (a.up) CH_LAUNCH(true, true) else CH_LAUNCH(true, false) }
 #undef CH_LAUNCH

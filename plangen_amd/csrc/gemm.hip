@@ -167,7 +167,7 @@ template <typename T> struct BigDispatch;
 template <> struct BigDispatch<bf16> {
     static void run(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e,
                     int M, int N, int K, int batch, int batch2, long strideB2) {
-        if (batch == 1 && batch2 == 1 && g_gemm256 && conv_halo_try(s, a, W, e, M, N, K)) return;
+        if (batch == 1 && batch2 == 1 && g_gemm256 && conv_halo_try(s, a, W, e, M, N, K, (float*)a.gn_part, a.gn_nsplit)) return;
         if (gemm256_try(s, a, W, ldb, strideB, e, M, N, K, batch, batch2, strideB2)) return;
         Epi<bf16> ep{e, M, N};
         const int ntm = (M + BIG_BM - 1) / BIG_BM, ntn = (N + BIG_BN - 1) / BIG_BN;

@@ -133,6 +133,29 @@ struct Epi {
         const long ldr = e.ldr ? e.ldr : e.ldc;
         return ((e.ldc | coff | ldr | roff) & 3) == 0 && (N & 3) == 0;
     }
+    // vector path of store4 split in two for kernels that also want the stored values (GroupNorm partials):
+    // in-range rows / columns and vec_ok() layouts only
+    __device__ __forceinline__ f32x4 final4(long roff, int row, int col, f32x4 v) const {
+        v *= e.scale;
+        if (e.bias_n) v += *(const f32x4*)(e.bias_n + col);
+        if (e.bias_m) v += e.bias_m[row];
+        if (e.residual) {
+            const long ldr = e.ldr ? e.ldr : e.ldc;
+            const long ro = roff + (long)row * ldr + col;
+            if (e.res_f32 || sizeof(T) == 4) v += *(const f32x4*)((const float*)e.residual + ro);
+            else {
+                const uint2 r2 = *(const uint2*)((const bf16*)e.residual + ro);
+                v += (f32x4){bf16_lo(r2.x), bf16_hi(r2.x), bf16_lo(r2.y), bf16_hi(r2.y)};
+            }
+        }
+        if (e.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+        return v;
+    }
+    __device__ __forceinline__ void put4(long coff, int row, int col, f32x4 v) const {
+        const long o = coff + (long)row * e.ldc + col;
+        if (e.out_f32 || sizeof(T) == 4) *(f32x4*)((float*)e.out + o) = v;
+        else { uint2 q; q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); *(uint2*)((bf16*)e.out + o) = q; }
+    }
     __device__ __forceinline__ void store4(long coff, long roff, int row, int col, f32x4 v, bool vec) const {
         if (row >= M || col >= N) return;
         if (!vec) {

@@ -19,6 +19,8 @@ struct GemmA {
     long strideA2 = 0;                  // second batch dimension (e.g. attention heads)
     int Hi = 0, Wi = 0, Cin = 0, up = 0;
     const void* zeros = nullptr;        // >= 256 B of zeros (conv halo source)
+    void* gn_part = nullptr;            // optional: GroupNorm partials of the OUTPUT (kernels that support it set *gn_nsplit > 0)
+    int* gn_nsplit = nullptr;
 };
 // Epilogue: v = acc*scale + bias_n[col] + bias_m[row] + residual[row,col]; act; store.
 struct GemmEpi {
@@ -42,7 +44,12 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
                  int batch, int batch2, long strideB2);
 extern int g_gemm256;
 // direct 3x3 convolution with an LDS-resident input halo tile (conv_halo.hip), Cin = Cout = 128
-bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K);
+// gn_part (optional, fp32 output only): per-(image, tile, group) GroupNorm partial sums of the stored tensor,
+// layout [B][*gn_nsplit][32][2] -- the input gn_finalize_kernel expects.
+bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K, float* gn_part = nullptr,
+                   int* gn_nsplit = nullptr);
+void launch_gn_finalize(hipStream_t s, const float* ws, float* stats, float* coef, const float* gamma, const float* beta, int B,
+                        int nsplit, int HW, int C, float eps);
 extern int g_conv_halo;
 bool conv_out_halo_try(hipStream_t s, const bf16* x, const bf16* w, const float* bias, const bf16* zeros, void* out, int out_bf16,
                        int B, int H, int Wd, int Cin, int Cout);

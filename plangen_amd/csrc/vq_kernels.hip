@@ -97,6 +97,10 @@ __global__ void gn_finalize_kernel(const float* __restrict__ ws, float* __restri
         }
     }
 }
+void launch_gn_finalize(hipStream_t s, const float* ws, float* stats, float* coef, const float* gamma, const float* beta, int B,
+                        int nsplit, int HW, int C, float eps) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, ws, stats, coef, gamma, beta, nsplit, (double)HW * (C / 32), eps, C);
+}
 static int gn_nsplit(int HW) { int n = (HW + 1023) / 1024; return n < 1 ? 1 : (n > 256 ? 256 : n); }
 void launch_gn_stats(hipStream_t s, const void* x, int is_bf16, float* stats, float* ws, int B, int HW, int C, float eps,
                      float* coef, const float* gamma, const float* beta) {
