@@ -408,7 +408,7 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
         hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8, 8>), dim3(nh, M), dim3(512), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
                            st, nh, slots, max_pos, scale);
     else
-        hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8, 4>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
+        hipLaunchKernelGGL((attn_decode_fused_kernel<T, 7, 4>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
                            st, nh, slots, max_pos, scale);
 }
 template void launch_attn_decode_fused<float>(hipStream_t, const float*, int, long, float*, float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
