@@ -699,6 +699,14 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
             if (sk && M <= 512 && Hh % 128 == 0 && (force_swiglu || skinny_pick_splits(2 * I, Hh, M) == 1))   // fused wins at every M (B=4/8/16: -2..3 % loop time)
                 fused = launch_gemm_skinny_swiglu(s, (const bf16*)xn, (const bf16*)ly.wgu, (bf16*)hbuf, M, 2 * I, Hh, (const bf16*)ly.wgu_t);
         }
+        if constexpr (std::is_same<T, bf16>::value) {
+            // prefill: SwiGLU in the 256x256 GEMM's epilogue (h written as bf16, no fp32 gate|up tensor, no extra pass)
+            if (!fused && !sk && (I % 4) == 0) {
+                GemmA ga; ga.ptr = xn; ga.lda = Hh;
+                GemmEpi ge; ge.out = hbuf; ge.out_f32 = 0; ge.ldc = I; ge.act = 2;
+                fused = gemm256_try(s, ga, (const bf16*)ly.wgu, Hh, 0, ge, M, 2 * I, Hh, 1, 1, 0);
+            }
+        }
         if (!fused) {
             gemm_llm<T>(s, (const T*)xn, (const T*)ly.wgu, M, 2 * I, Hh, sk, ly.wgu_t);
             launch_silu_mul<T>(s, part, S_last, slab_last, (T*)hbuf, M, I);

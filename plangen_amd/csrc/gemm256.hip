@@ -201,14 +201,39 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
         // every wave is past its last ds_read: the next tile's first loads go out before this tile's
         // stores (same vmcnt counter, but loads return in order among themselves and the clamped tail
         // stages of this tile were issued earlier by the same wave to the same LDS bytes)
-        const int em0 = m0 + wr * 128 + lr, en0 = n0 + wc * 64 + g * 4;
+        const int em0 = m0 + wr * 128 + lr, en0 = n0 + wc * 64 + g * 4, ecol0 = n0 + wc * 64;   // setup() below moves m0 / n0 on
         base += G;
         have = base < NT && setup(base);
         if (have) prologue();
+        if (ep.e.act == 2) {
+            // SwiGLU epilogue: W rows are interleaved [8 gate | 8 up] per 16-column n-tile (the engine's gate|up
+            // layout), so lanes g = 0,1 hold 4 gate columns and lanes g = 2,3 (lane ^ 32) the matching 4 up columns
+            // of the same row: one cross-half exchange, then h = silu(gate) * up goes out as 4 bf16 (8 bytes)
+            // at column n/2 -- the fp32 gate|up tensor is never written.  out: bf16 [M, N/2], ldc = N/2.
+            bf16* hout = (bf16*)ep.e.out + coff;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+            for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) ep.store4(coff, roff, em0 + mt * 16, en0 + nt * 16, acc[mt][nt], vec);
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x4 v = acc[mt][nt];
+                    f32x4 u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(v[j], 32, 64);
+                    const int row = em0 + mt * 16, col = (ecol0 + nt * 16) / 2 + g * 4;
+                    if (g < 2 && row < M && col < N / 2) {
+                        float hh[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hh[j] = (v[j] / (1.f + expf(-v[j]))) * u[j];
+                        uint2 q; q.x = pack_bf16x2(hh[0], hh[1]); q.y = pack_bf16x2(hh[2], hh[3]);
+                        *(uint2*)(hout + (long)row * ep.e.ldc + col) = q;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) ep.store4(coff, roff, em0 + mt * 16, en0 + nt * 16, acc[mt][nt], vec);
+        }
     }
 #undef G2_MFMA_SECTION
 #undef G2_WAIT

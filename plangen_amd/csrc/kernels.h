@@ -33,7 +33,7 @@ struct GemmEpi {
     int res_f32 = 0;
     long ldr = 0, strideR = 0;
     float scale = 1.f;
-    int act = 0;                        // 0 none, 1 gelu(erf)
+    int act = 0;                        // 0 none, 1 gelu(erf); 2 (256x256 kernel only) SwiGLU over [8 gate | 8 up] column blocks -> bf16 [M, N/2]
 };
 template <typename T>
 void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strideB,

@@ -217,3 +217,29 @@ def test_mmu_and_uni_2stage_full_size_properties():
     idx = e.vq_encode(img.float().clamp(-1, 1))
     assert idx.numel() == cfg.img_tokens and ((idx >= 0) & (idx < cfg.img_vocab)).all()
     del e
+
+
+def test_prefill_big_tile_kernels_equal_small_tile_kernels():
+    """A packed prefill large enough (>= 200 tiles of 256x256) to run its GEMMs on the eight-phase kernel,
+    including the SwiGLU-in-the-epilogue gate|up GEMM: every hidden state must equal the 128x128-kernel path
+    bit for bit (same K order, same fp32 silu), ragged prompts included."""
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    cfg = PlanGenConfig.janus_pro_1b()
+    e = Engine(cfg, dtype="bf16", max_rows=16, max_prompt=160, max_new=4, max_images=1)
+    e.init_synthetic(seed=0)
+    g = torch.Generator().manual_seed(9)
+    R, L = 16, 160
+    ids = torch.randint(10, 100000, (R, L), generator=g).int()
+    pad = [int(v) for v in torch.randint(0, 40, (R,), generator=g)]
+    e.set_option("share_uncond", 0)
+    e.set_option("gemm256", 1)
+    h1 = e.prefill(ids, pad, return_hidden=True).clone()
+    e.set_option("gemm256", 0)
+    h0 = e.prefill(ids, pad, return_hidden=True).clone()
+    e.set_option("gemm256", 1)
+    e.set_option("share_uncond", 1)
+    assert torch.isfinite(h1).all()
+    for r in range(R):
+        assert torch.equal(h1[r, pad[r]:], h0[r, pad[r]:]), r
+    del e
