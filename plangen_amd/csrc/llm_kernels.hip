@@ -404,7 +404,7 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
                               int max_pos, float scale) {
     if (M <= 0) return;
     // few (row, head) blocks (small batch): eight waves per block keep 2x the K/V bytes in flight per CU
-    if (M * nh <= 512 && g_attn_waves != 4)
+    if ((M * nh <= 512 && g_attn_waves != 4) || g_attn_waves == 8)
         hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8, 8>), dim3(nh, M), dim3(512), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
                            st, nh, slots, max_pos, scale);
     else
