@@ -184,6 +184,7 @@ int pg_get_timing(pg_handle h, pg_timing* out);
  *   flash_prefill (1)   MFMA flash attention for prefill (0: per-query streaming kernel)
  *   fuse_rope (1)       RoPE + KV append inside the decode-attention kernel
  *   lanes (1)           2: two row-range lanes on two streams
+ *   cu_split (0)        with lanes=2: complementary CU masks on the lane streams (1-4: mask patterns)
  *   lpt_order (1)       longest rows first in the decode-attention launch
  *   attn_variant, attn_waves (0; 4 pins 4-wave blocks)   decode-attention kernel variants
  *   gemm256 (1)         256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)

@@ -117,7 +117,7 @@ struct pg_engine {
     hipGraphExec_t gexec = nullptr; std::vector<int64_t> gkey;
     hipGraphExec_t gexec_txt = nullptr; std::vector<int64_t> gkey_txt;      // text-decode step (lm_head + argmax + stack)
     void drop_graphs() { if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; } if (gexec_txt) { (void)hipGraphExecDestroy(gexec_txt); gexec_txt = nullptr; } }
-    bool use_graph = true; bool time_attn = false; bool fuse_rope = true; bool force_swiglu = true; bool gn_fuse = true;
+    bool use_graph = true; bool time_attn = false; bool fuse_rope = true; bool force_swiglu = true; bool gn_fuse = true; int cu_split = 0;
     std::vector<hipEvent_t> attn_ev; size_t attn_ev_used = 0; std::vector<double> attn_ev_bytes;
     pg_timing timing{};
     bool have_decode_t = false, have_prefill_t = false, have_vq_t = false;
@@ -829,7 +829,10 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     // weights are read twice) -> one lane unless asked for (pg_set_option "lanes").
     int nl = lanes_opt > 0 ? lanes_opt : 1;
     if (Rtot % 4 || (long)decode_part_elems <= 0) nl = 1;
-    const bool graph = use_graph && !time_attn && T > 2;
+    // cu_split: the two lanes own disjoint CU sets (streams created with a CU mask) and run their whole loops
+    // independently (no per-step join, no graph: graph nodes do not carry the masks)
+    const bool free_lanes = nl == 2 && cu_split > 0 && !time_attn;
+    const bool graph = use_graph && !time_attn && T > 2 && !free_lanes;
     struct LaneDef { int r0, nrows; float* part; int32_t* ndec; };
     LaneDef ld[2];
     ld[0] = {0, nl == 2 ? Rtot / 2 : Rtot, part, d_ndec};
@@ -875,7 +878,7 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     // In time_attn mode the lanes run back to back on one stream so the per-launch events are clean.
     const bool two_streams = nl == 2 && !time_attn;
     auto iteration = [&](bool with_forward) -> int {
-        if (two_streams) { HIPCHK(hipEventRecord(ev_fork, ws)); HIPCHK(hipStreamWaitEvent(istream2, ev_fork, 0)); }
+        if (two_streams && !free_lanes) { HIPCHK(hipEventRecord(ev_fork, ws)); HIPCHK(hipStreamWaitEvent(istream2, ev_fork, 0)); }
         for (int li = 0; li < nl; ++li) {
             hipStream_t st = (two_streams && li == 1) ? istream2 : ws;
             enter(ld[li]);
@@ -883,10 +886,11 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
             if (with_forward) forward_decode(st);
             leave();
         }
-        if (two_streams) { HIPCHK(hipEventRecord(ev_join, istream2)); HIPCHK(hipStreamWaitEvent(ws, ev_join, 0)); }
+        if (two_streams && !free_lanes) { HIPCHK(hipEventRecord(ev_join, istream2)); HIPCHK(hipStreamWaitEvent(ws, ev_join, 0)); }
         return PG_OK;
     };
     HIPCHK(hipEventRecord(ev_t0, ws));
+    if (free_lanes) { HIPCHK(hipEventRecord(ev_fork, ws)); HIPCHK(hipStreamWaitEvent(istream2, ev_fork, 0)); }
     TRY(iteration(T > 1));
     if (T > 1) n_dec_host++;
     int i = 1;
@@ -912,6 +916,7 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
         for (; i < T - 1; ++i) { TRY(iteration(true)); n_dec_host++; }
     }
     if (T > 1) TRY(iteration(false));
+    if (free_lanes) { HIPCHK(hipEventRecord(ev_join, istream2)); HIPCHK(hipStreamWaitEvent(ws, ev_join, 0)); }
     HIPCHK(hipEventRecord(ev_t1, ws));
     if (ws != s) {
         HIPCHK(hipEventRecord(ev_out, ws));
@@ -1362,6 +1367,32 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
     if (!strcmp(key, "gemm256")) { g_gemm256 = (int)value; return PG_OK; }
     if (!strcmp(key, "conv_halo")) { g_conv_halo = (int)value; return PG_OK; }
+    if (!strcmp(key, "cu_split")) {
+        // lane streams with complementary CU masks: 1 = low / high half of the mask bits, 2 = even / odd bits,
+        // 3 = alternating groups of 32 bits, 4 = alternating groups of 8 bits; 0 = unmasked streams
+        (void)hipSetDevice(h->dev);
+        h->drop_graphs();
+        (void)hipStreamSynchronize(h->istream); (void)hipStreamSynchronize(h->istream2);
+        (void)hipStreamDestroy(h->istream); (void)hipStreamDestroy(h->istream2);
+        h->cu_split = (int)value;
+        if (value == 0) {
+            if (hipStreamCreateWithFlags(&h->istream, hipStreamNonBlocking) != hipSuccess) return PG_ERR_HIP;
+            if (hipStreamCreateWithFlags(&h->istream2, hipStreamNonBlocking) != hipSuccess) return PG_ERR_HIP;
+        } else {
+            uint32_t m0[8], m1[8];
+            for (int i = 0; i < 8; ++i) {
+                uint32_t a;
+                if (value == 1) a = i < 4 ? 0xffffffffu : 0u;
+                else if (value == 2) a = 0x55555555u;
+                else if (value == 3) a = (i & 1) ? 0u : 0xffffffffu;
+                else a = 0x00ff00ffu;
+                m0[i] = a; m1[i] = ~a;
+            }
+            if (hipExtStreamCreateWithCUMask(&h->istream, 8, m0) != hipSuccess) return PG_ERR_HIP;
+            if (hipExtStreamCreateWithCUMask(&h->istream2, 8, m1) != hipSuccess) return PG_ERR_HIP;
+        }
+        return PG_OK;
+    }
     if (!strcmp(key, "gn_fuse")) { h->gn_fuse = value != 0; return PG_OK; }
     if (!strcmp(key, "attn_waves")) { g_attn_waves = (int)value; h->drop_graphs(); return PG_OK; }
     if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; h->drop_graphs(); return PG_OK; }
