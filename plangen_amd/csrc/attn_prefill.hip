@@ -152,3 +152,105 @@ void launch_attn_prefill_flash(hipStream_t s, const bf16* qbuf, bf16* obuf, cons
     hipLaunchKernelGGL(attn_prefill_flash_kernel, dim3((max_len + 63) / 64, nh, R), dim3(256), 0, s, qbuf, obuf, kc, vc, row_off, len,
                        nh, slots, scale);
 }
+
+// ------------------------------------------------------------------------------- SigLIP (ViT) attention
+// Non-causal flash attention for the understanding encoder (siglip_vit.py:164-192): head_dim 64, P tokens per
+// image (P % 64 == 0), bf16.  Same MFMA scheme as the prefill kernel above (swapped QK^T so P stays in
+// registers, per-query statistics with two cross-lane steps); q | k come from the fused [M, 2C] projection,
+// V^T from the [B][C][P] tensor the encoder's V projection already writes (key-contiguous rows: staged
+// without a transpose).  Scores are scaled in fp32 after the MFMA, like the softmax kernel it replaces.
+#define VA_ROW 144           // bytes per LDS row (64 x bf16 + 16 pad)
+__global__ __launch_bounds__(256) void attn_vit_flash_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt,
+                                                            bf16* __restrict__ o, int P, int C, float scale) {
+    __shared__ __attribute__((aligned(16))) char sK[64 * VA_ROW];
+    __shared__ __attribute__((aligned(16))) char sV[64 * VA_ROW];
+    const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
+    const int q0 = qt * 64 + w * 16, myq = q0 + lr;
+    bf16x8 qf[2];
+    {
+        const bf16* qp = qk + ((long)b * P + myq) * 2 * C + head * 64 + g * 8;
+        qf[0] = *(const bf16x8*)qp; qf[1] = *(const bf16x8*)(qp + 32);
+    }
+    const bf16* kbase = qk + (long)b * P * 2 * C + C + head * 64;
+    const bf16* vbase = vt + ((long)b * C + head * 64) * P;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int kb = 0; kb < P; kb += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int v = tid + j * 256, r = v >> 3, cv = v & 7;            // 64 rows x 8 chunks of 16 B
+            *(u32x4*)(sK + r * VA_ROW + cv * 16) = *(const u32x4*)(kbase + (long)(kb + r) * 2 * C + cv * 8);
+            *(u32x4*)(sV + r * VA_ROW + cv * 16) = *(const u32x4*)(vbase + (long)r * P + kb + cv * 8);
+        }
+        __syncthreads();
+        f32x4 sacc[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            sacc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < 2; ++ds) {
+                const bf16x8 ka = *(const bf16x8*)(sK + (kt * 16 + lr) * VA_ROW + (ds * 32 + g * 8) * 2);
+                sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ds], sacc[kt], 0, 0, 0);
+            }
+        }
+        float mx = m_run;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sacc[kt][r] *= scale; mx = fmaxf(mx, sacc[kt][r]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float alpha = __expf(m_run - mx);
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float p[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                p[r] = __expf(sacc[2 * s2][r] - mx);
+                p[4 + r] = __expf(sacc[2 * s2 + 1][r] - mx);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) psum += p[e];
+            const u32x4 pv = ET<bf16>::pack(p);
+            pf[s2] = *(const bf16x8*)&pv;
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = mx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt][r] *= a;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* vr = sV + (dt * 16 + lr) * VA_ROW;
+                const u32x2 lo = *(const u32x2*)(vr + ((2 * s2) * 16 + g * 4) * 2);
+                const u32x2 hi = *(const u32x2*)(vr + ((2 * s2 + 1) * 16 + g * 4) * 2);
+                u32x4 vb; vb.x = lo.x; vb.y = lo.y; vb.z = hi.x; vb.w = hi.y;
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[s2], *(const bf16x8*)&vb, oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float inv = 1.f / __shfl(l_run, g * 4 + r, 64);
+        bf16* op = o + ((long)b * P + q0 + g * 4 + r) * C + head * 64 + lr;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ET<bf16>::st(op + dt * 16, oacc[dt][r] * inv);
+    }
+}
+// qk [B*P, 2C] (q | k), vt [B][C][P] (V transposed), o [B*P, C]; heads of 64; P % 64 == 0.
+void launch_attn_vit_flash(hipStream_t s, const bf16* qk, const bf16* vt, bf16* o, int B, int P, int C, int NH, float scale) {
+    hipLaunchKernelGGL(attn_vit_flash_kernel, dim3(P / 64, NH, B), dim3(256), 0, s, qk, vt, o, P, C, scale);
+}

@@ -1216,6 +1216,14 @@ int pg_engine::vision_encode(const void* img, int img_dtype, void* out, int out_
             GemmEpi ev; ev.out = vvt; ev.out_f32 = 0; ev.ldc = P; ev.strideC = (long)C * P; ev.bias_m = w.qkv.b + 2 * C;
             launch_gemm<T>(s, av, (const T*)vt, C, (long)P * C, ev, C, P, C, B);
         }
+        bool vflash = false;
+        if constexpr (std::is_same<T, bf16>::value) {
+            if (flash_prefill && C / NH == 64 && P % 64 == 0) {      // fused non-causal flash attention (no score tensor)
+                launch_attn_vit_flash(s, (const bf16*)vqk, (const bf16*)vvt, (bf16*)vo, B, P, C, NH, scale);
+                vflash = true;
+            }
+        }
+        if (!vflash) {
         {   // scores[b,h] = q[b,:,h] . k[b,:,h]^T / sqrt(64)   (non-causal SDPA, siglip_vit.py:178-183)
             GemmA a; a.ptr = vqk; a.lda = 2 * C; a.strideA = (long)P * 2 * C; a.strideA2 = 64;
             GemmEpi e; e.out = vscore; e.out_f32 = 1; e.ldc = P; e.strideC = (long)NH * P * P; e.strideC2 = (long)P * P;
@@ -1226,6 +1234,7 @@ int pg_engine::vision_encode(const void* img, int img_dtype, void* out, int out_
             GemmA a; a.ptr = vp; a.lda = P; a.strideA = (long)NH * P * P; a.strideA2 = (long)P * P;
             GemmEpi e; e.out = vo; e.out_f32 = 0; e.ldc = C; e.strideC = (long)P * C; e.strideC2 = 64;
             launch_gemm<T>(s, a, (const T*)vvt, P, (long)C * P, e, P, 64, P, B, NH, (long)64 * P);
+        }
         }
         lin<T>(s, w.proj, (const T*)vo, vx, 1, vx, 1, 0, M);                      // x += proj(o)
         launch_layernorm<T>(s, vx, w.n2.g, w.n2.b, (T*)vt, (int)M, C, 1e-6f);

@@ -43,6 +43,7 @@ void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strid
 bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e, int M, int N, int K,
                  int batch, int batch2, long strideB2);
 extern int g_gemm256;
+void launch_attn_vit_flash(hipStream_t s, const bf16* qk, const bf16* vt, bf16* o, int B, int P, int C, int NH, float scale);
 // direct 3x3 convolution with an LDS-resident input halo tile (conv_halo.hip), Cin = Cout = 128
 // gn_part (optional, fp32 output only): per-(image, tile, group) GroupNorm partial sums of the stored tensor,
 // layout [B][*gn_nsplit][32][2] -- the input gn_finalize_kernel expects.
