@@ -73,12 +73,19 @@ __global__ void gn_finalize_kernel(const float* __restrict__ ws, float* __restri
                                    double cnt, float eps, int C) {
     __shared__ float s_mean[32], s_rstd[32];
     const int b = blockIdx.x, t = threadIdx.x;
-    if (t < 32) {
-        double s = 0.0, q = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp) {
-            const float* o = ws + (((long)b * nsplit + sp) * 32 + t) * 2;
+    // 8 threads per group walk the partials (up to 1024 conv tiles per image) and meet in three shuffles:
+    // fixed order, double accumulation
+    const int grp = t >> 3, sub = t & 7;
+    double s = 0.0, q = 0.0;
+    if (grp < 32)
+        for (int sp = sub; sp < nsplit; sp += 8) {
+            const float* o = ws + (((long)b * nsplit + sp) * 32 + grp) * 2;
             s += (double)o[0]; q += (double)o[1];
         }
+#pragma unroll
+    for (int o_ = 1; o_ < 8; o_ <<= 1) { s += __shfl_xor(s, o_, 64); q += __shfl_xor(q, o_, 64); }
+    if (grp < 32 && sub == 0) {
+        const int t = grp;
         const double mean = s / cnt;
         double var = q / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
