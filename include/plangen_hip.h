@@ -205,7 +205,15 @@ int pg_op_rmsnorm(pg_handle h, float* x_dev /*[M,H] in/out*/, const float* parti
                   int S, const void* w_dev /*compute dtype [H]*/, void* out_dev /*compute dtype [M,H]*/,
                   int M, int H, float eps, pg_stream s);
 int pg_op_gemm(pg_handle h, const void* a_dev /*[M,K]*/, const void* w_dev /*[N,K]*/, float* out_dev /*[S,M,N]*/,
-               int M, int N, int K, int force_kind /*0 auto,1 skinny,2 big,3 f32*/, int* S_out, pg_stream s);
+               int M, int N, int K, int force_kind /*0 auto,1 skinny,2 big,3 f32,4 skinny on the tiled decode copy of W*/,
+               int* S_out, pg_stream s);
+/* The decode gate|up GEMM with SwiGLU in its epilogue (transformers LlamaMLP: down(silu(gate(x)) * up(x))):
+ * a_dev bf16 [M,K]; wgu_dev bf16 [2I,K] with gate/up rows interleaved in blocks of 8 (rows 16j..16j+7 = gate rows
+ * 8j..8j+7, rows 16j+8..16j+15 = the matching up rows: the engine's internal layout); h_out_dev bf16 [M,I]. */
+int pg_op_swiglu_gemm(pg_handle h, const void* a_dev, const void* wgu_dev, void* h_out_dev, int M, int I, int K, pg_stream s);
+/* The sampler's RNG output stage: raw 64-bit generator outputs bits_dev [n] -> out_dev fp32 [2n] =
+ * (uniform u in (0,1) | Gumbel noise -log(-log u)) exactly as cfg_scan_kernel computes them. */
+int pg_op_uniform(pg_handle h, const uint64_t* bits_dev, float* out_dev, int n, pg_stream s);
 
 /* 3x3 convolution over NHWC activations (compute dtype), the VQ-16 ResnetBlock / Upsample /
  * Downsample conv (vq_model.py:337-352, :417-427, :440-447).  w_dev is [Cout][9][Cin]

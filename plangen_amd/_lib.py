@@ -57,6 +57,8 @@ SYMBOLS = [
     ("pg_debug_read", C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_int64, _P]),
     ("pg_op_rmsnorm", C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_float, _P]),
     ("pg_op_gemm", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), _P]),
+    ("pg_op_swiglu_gemm", C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    ("pg_op_uniform", C.c_int, [_P, _P, _P, C.c_int, _P]),
     ("pg_op_conv3x3", C.c_int, [_P, _P, _P, _P, _P, _P] + [C.c_int] * 7 + [_P]),
     ("pg_op_groupnorm", C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
 ]

@@ -115,21 +115,21 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     GemmA ga; ga.ptr = A; ga.lda = K;
     if (conv) { ga.kind = 1; ga.Hi = Hi; ga.Wi = Wi; ga.Cin = Cin; ga.up = up; ga.zeros = zeros; }
     GemmEpi e; e.out = o0; e.out_f32 = 1; e.ldc = N;
-    const int saved = g_gemm256;
-    if (getenv("PG_CONV_HALO")) g_conv_halo = atoi(getenv("PG_CONV_HALO"));
+    PgTune tune; const PgTune* const saved = pg_tune; pg_tune = &tune;
+    if (getenv("PG_CONV_HALO")) tune.conv_halo = atoi(getenv("PG_CONV_HALO"));
     hipDeviceSynchronize();
     if (verify) {
         hipMalloc((void**)&o1, (long)M * N * 4);
-        g_gemm256 = 0; e.out = o1; launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
+        tune.gemm256 = 0; e.out = o1; launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
         // race screen: `verify` independent launches, each compared element-wise with the 128x128 result
         for (int v = 0; v < verify; ++v) {
-            g_gemm256 = mode ? mode : 1; e.out = o0; hipMemsetAsync(o0, 0xff, (long)M * N * 4, s); launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
+            tune.gemm256 = mode ? mode : 1; e.out = o0; hipMemsetAsync(o0, 0xff, (long)M * N * 4, s); launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
             hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, s, o0, o1, (long)M * N, md);
         }
         hipStreamSynchronize(s);
         hipMemcpy(maxdiff_out, md, 4, hipMemcpyDeviceToHost);
     }
-    g_gemm256 = mode; e.out = o0;
+    tune.gemm256 = mode; e.out = o0;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) launch_gemm<bf16>(s, ga, Wt, K, 0, e, M, N, K, 1);
     hipEventRecord(e0, s);
@@ -137,7 +137,7 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     hipEventRecord(e1, s); hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     *us_out = ms * 1000.f / iters;
-    g_gemm256 = saved;
+    pg_tune = saved;
     const int rc = hipGetLastError() == hipSuccess ? 0 : -1;
     hipFree(A); hipFree(Wt); hipFree(zeros); hipFree(o0); if (o1) hipFree(o1); hipFree(md);
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);

@@ -100,13 +100,21 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-// Counter-based RNG (splitmix64 finaliser) -> uniform (0,1)
-__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t a, uint64_t b) {
+// Counter-based RNG (splitmix64 finaliser) -> uniform strictly inside (0,1).
+// 23 random bits: x + 0.5 with x < 2^23 is exact in fp32 (24-bit significand), so
+// u in [2^-24, 1 - 2^-24].  (24 bits would round 16777215.5 up to 2^24 -> u == 1.0 ->
+// Gumbel noise +inf.)
+__device__ __forceinline__ uint64_t rng_bits(uint64_t seed, uint64_t a, uint64_t b) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xBF58476D1CE4E5B9ull * (b + 1);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float uniform_from_bits(uint64_t z) {
+    return ((float)(z >> 41) + 0.5f) * (1.0f / 8388608.0f);
+}
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t a, uint64_t b) {
+    return uniform_from_bits(rng_bits(seed, a, b));
 }
 
 // One row of (split-K reduce + residual add + RMSNorm) by a 256-thread block (rmsnorm_kernel and the

@@ -221,12 +221,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-int g_conv_halo = 1;        // pg_set_option("conv_halo", 0/1)
 
 // Takes 3x3 / pad 1 / stride 1 convolutions with Cin = Cout = 128 on images whose sides are multiples of the
 // 8 x 32 tile; returns false otherwise (the implicit-GEMM kernels handle the rest).
 bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& e, int M, int N, int K, float* gn_part, int* gn_nsplit) {
-    if (!g_conv_halo || a.kind != 1 || a.up > 1 || a.Cin != 128 || N != 128 || K != 9 * 128) return false;
+    if (!pg_tune->conv_halo || a.kind != 1 || a.up > 1 || a.Cin != 128 || N != 128 || K != 9 * 128) return false;
     const int H = a.Hi << a.up, Wd = a.Wi << a.up;                 // output size
     if (H % CH_TH || Wd % CH_TW || a.strideA || e.strideC) return false;
     const long px = (long)H * Wd;
@@ -245,7 +244,7 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
     }
     if (gn_part && !(e.out_f32 && (e.ldc & 3) == 0)) gn_part = nullptr;
     if (gn_nsplit) *gn_nsplit = gn_part ? (H / CH_TH) * (Wd / CH_TW) : 0;
-    if (g_conv_halo == 2) { if (a.up) CH_LAUNCH(false, true) else CH_LAUNCH(false, false) }
+    if (pg_tune->conv_halo == 2) { if (a.up) CH_LAUNCH(false, true) else CH_LAUNCH(false, false) }
     else { if (a.up) CH_LAUNCH(true, true) else CH_LAUNCH(true, false) }
 #undef CH_LAUNCH
     return true;
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(512) void conv3x3_out_halo_kernel(const bf16* __res
 
 bool conv_out_halo_try(hipStream_t s, const bf16* x, const bf16* w, const float* bias, const bf16* zeros, void* out, int out_bf16,
                        int B, int H, int Wd, int Cin, int Cout) {
-    if (!g_conv_halo || Cin != 128 || Cout > 4 || H % CH_TH || Wd % CH_TW) return false;
+    if (!pg_tune->conv_halo || Cin != 128 || Cout > 4 || H % CH_TH || Wd % CH_TW) return false;
     const int tiles = B * (H / CH_TH) * (Wd / CH_TW);
     if (tiles < 64) return false;
     auto kfn = conv3x3_out_halo_kernel;

@@ -47,6 +47,7 @@ struct Slot {
     void* dst = nullptr; SlotKind kind = K_T; long n = 0;
     int a = 0, b = 0, c = 0;
     bool loaded = false;
+    std::vector<int64_t> shape;       // expected state_dict shape (empty: only the element count is checked)
 };
 struct ConvW { void* w = nullptr; float* b = nullptr; int cin = 0, cout = 0, k = 3; };
 struct NormW { float* g = nullptr; float* b = nullptr; int c = 0; };
@@ -88,6 +89,7 @@ struct pg_engine {
     float *cos_t = nullptr, *sin_t = nullptr; int max_pos = 0;
     void* zeros = nullptr;
     bool finalized = false;
+    bool allow_partial = false;       // pg_set_option("allow_partial_weights", 1): run with missing tensors (they read as zeros)
 
     // ---- sequence state
     int R = 0, L = 0, Ntok = 0, slots = 0; bool prefilled = false; int pos_mode = 0;
@@ -96,8 +98,14 @@ struct pg_engine {
     int32_t *d_len = nullptr, *d_pos_off = nullptr, *d_ndec = nullptr, *d_tok_row = nullptr, *d_tok_j = nullptr,
             *d_tok_src = nullptr, *d_last = nullptr, *d_unf = nullptr, *d_anyunf = nullptr, *d_row_off = nullptr;
     int max_len_host = 0; bool flash_prefill = true;
-    int32_t* h_stage = nullptr;                                  // pinned host staging
+    int32_t* h_stage2[2] = {nullptr, nullptr};                   // pinned host staging, double-buffered
+    hipEvent_t ev_stage[2] = {nullptr, nullptr}; bool stage_used[2] = {false, false}; int stage_sel = 0;
+    int32_t* d_flag = nullptr; int32_t* h_flag = nullptr;        // uncond-sharing probe result
     float* cfg_pv = nullptr; int* cfg_pi = nullptr;              // sampler stage-1 winners
+    SampleParams* d_sparams = nullptr; TextParams* d_tparams = nullptr;   // per-call parameters the graphs read from HBM
+    int32_t *d_out_tok = nullptr, *d_force_tok = nullptr; uint8_t* d_force_mask = nullptr; int64_t* d_text_out = nullptr;
+    PgTune tune;                                                 // per-handle tuning knobs (pg_set_option)
+    int tune_epoch = 0;                                          // bumped by every option that changes what a captured graph contains
     void* kv = nullptr;
     // ---- workspaces
     long max_tok = 0;
@@ -123,10 +131,11 @@ struct pg_engine {
     bool have_decode_t = false, have_prefill_t = false, have_vq_t = false;
     int S_last = 1; long slab_last = 0;
 
-    template <typename U> int dalloc(U** p, size_t n_bytes) {
+    template <typename U> int dalloc(U** p, size_t n_bytes, bool zero = true) {
         void* q = nullptr;
         if (n_bytes == 0) n_bytes = 16;
         HIPCHK(hipMalloc(&q, n_bytes));
+        if (zero) HIPCHK(hipMemsetAsync(q, 0, n_bytes, nullptr));      // weights never loaded read as zeros, not as stale HBM
         allocs.push_back(q); bytes += (int64_t)n_bytes; *p = (U*)q;
         return PG_OK;
     }
@@ -148,6 +157,7 @@ struct pg_engine {
 
     int create();
     void add_slot(const std::string& name, void* dst, SlotKind k, long n, int a = 0, int b = 0, int c = 0);
+    void slot_shape(const std::string& name, std::initializer_list<int64_t> shp) { slots_map[name].shape = shp; }
     int alloc_conv(const std::string& name, ConvW& cw, int cout, int cin, int k);
     int alloc_norm(const std::string& name, NormW& nw, int c);
     int alloc_res(const std::string& name, ResBlockW& r, int cin, int cout);
@@ -191,6 +201,7 @@ int pg_engine::alloc_conv(const std::string& name, ConvW& cw, int cout, int cin,
     TRY(dalloc(&cw.w, (size_t)cout * cin * k * k * esz));
     TRY(dalloc(&cw.b, (size_t)cout * 4));
     add_slot(name + ".weight", cw.w, k == 1 ? K_T : K_CONV, (long)cout * cin * k * k, cout, cin, k * k);
+    slot_shape(name + ".weight", {cout, cin, k, k});
     add_slot(name + ".bias", cw.b, K_F32, cout);
     return PG_OK;
 }
@@ -257,6 +268,7 @@ int pg_engine::build_vq() {
         TRY(dalloc(&enc_in_w, (size_t)ch * 27 * 4));
         TRY(dalloc(&enc_in_b, (size_t)ch * 4));
         add_slot(E + "conv_in.weight", enc_in_w, K_F32, (long)ch * 27);
+        slot_shape(E + "conv_in.weight", {ch, 3, 3, 3});
         add_slot(E + "conv_in.bias", enc_in_b, K_F32, ch);
         enc.levels.resize(nres);
         int b_in = ch;
@@ -284,6 +296,7 @@ int pg_engine::build_vq() {
         TRY(dalloc(&qc_w, (size_t)cfg.img_dim * cfg.vq_z * esz));
         TRY(dalloc(&qc_b, (size_t)cfg.img_dim * 4));
         add_slot(V + "quant_conv.weight", qc_w, K_T, (long)cfg.img_dim * cfg.vq_z);
+        slot_shape(V + "quant_conv.weight", {cfg.img_dim, cfg.vq_z, 1, 1});
         add_slot(V + "quant_conv.bias", qc_b, K_F32, cfg.img_dim);
     }
     return PG_OK;
@@ -294,6 +307,7 @@ int pg_engine::alloc_lin(const std::string& name, LinW& l, int out, int in) {
     TRY(dalloc(&l.w, (size_t)out * in * esz));
     TRY(dalloc(&l.b, (size_t)out * 4));
     add_slot(name + ".weight", l.w, K_T, (long)out * in);
+    slot_shape(name + ".weight", {out, in});
     add_slot(name + ".bias", l.b, K_F32, out);
     return PG_OK;
 }
@@ -353,6 +367,7 @@ int pg_engine::create() {
     const std::string LM = "language_model.model.";
     TRY(dalloc(&embed, (size_t)cfg.vocab * Hh * 4));
     add_slot(LM + "embed_tokens.weight", embed, K_F32, (long)cfg.vocab * Hh);
+    slot_shape(LM + "embed_tokens.weight", {cfg.vocab, Hh});
     layers.resize(cfg.n_layers);
     for (int i = 0; i < cfg.n_layers; ++i) {
         Layer& ly = layers[i];
@@ -370,6 +385,10 @@ int pg_engine::create() {
         add_slot(p + "mlp.gate_proj.weight", ly.wgu, K_IL16_G, (long)I * Hh, I, Hh);
         add_slot(p + "mlp.up_proj.weight", ly.wgu, K_IL16_U, (long)I * Hh, I, Hh);
         add_slot(p + "mlp.down_proj.weight", ly.wd, K_T, (long)Hh * I);
+        for (const char* nm : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight"}) slot_shape(p + nm, {HDm, Hh});
+        slot_shape(p + "self_attn.o_proj.weight", {Hh, HDm});
+        slot_shape(p + "mlp.gate_proj.weight", {I, Hh}); slot_shape(p + "mlp.up_proj.weight", {I, Hh});
+        slot_shape(p + "mlp.down_proj.weight", {Hh, I});
         add_slot(p + "input_layernorm.weight", ly.ln1, K_T, Hh);
         add_slot(p + "post_attention_layernorm.weight", ly.ln2, K_T, Hh);
     }
@@ -378,6 +397,7 @@ int pg_engine::create() {
     if (cfg.with_lm_head) {
         TRY(dalloc(&lm_head, (size_t)cfg.vocab * Hh * esz));
         add_slot("language_model.lm_head.weight", lm_head, K_T, (long)cfg.vocab * Hh);
+        slot_shape("language_model.lm_head.weight", {cfg.vocab, Hh});
     }
     const int G = cfg.gen_head_dim, V = cfg.img_vocab, Dm = cfg.img_dim;
     TRY(dalloc(&gh_w1, (size_t)G * Hh * esz));
@@ -388,6 +408,7 @@ int pg_engine::create() {
     add_slot("gen_head.output_mlp_projector.bias", gh_b1, K_F32, G);
     add_slot("gen_head.vision_head.weight", gh_w2, K_T, (long)V * G);
     add_slot("gen_head.vision_head.bias", gh_b2, K_F32, V);
+    slot_shape("gen_head.output_mlp_projector.weight", {G, Hh}); slot_shape("gen_head.vision_head.weight", {V, G});
     TRY(dalloc(&ge_w, (size_t)V * Dm * 4));
     TRY(dalloc(&al_w0, (size_t)Hh * Dm * 4));
     TRY(dalloc(&al_b0, (size_t)Hh * 4));
@@ -398,6 +419,7 @@ int pg_engine::create() {
     add_slot("gen_aligner.layers.0.bias", al_b0, K_F32, Hh);
     add_slot("gen_aligner.layers.2.weight", al_w2, K_F32, (long)Hh * Hh);
     add_slot("gen_aligner.layers.2.bias", al_b2, K_F32, Hh);
+    slot_shape("gen_embed.weight", {V, Dm}); slot_shape("gen_aligner.layers.0.weight", {Hh, Dm}); slot_shape("gen_aligner.layers.2.weight", {Hh, Hh});
     TRY(dalloc(&gen_table, (size_t)V * Hh * 4));
     TRY(dalloc(&codebook, (size_t)V * Dm * 4));
     TRY(dalloc(&codebook_n, (size_t)V * Dm * 4));
@@ -407,6 +429,7 @@ int pg_engine::create() {
     add_slot("gen_vision_model.quantize.embedding.weight", codebook, K_F32, (long)V * Dm);
     add_slot("gen_vision_model.post_quant_conv.weight", pq_w, K_F32, (long)cfg.vq_z * Dm);
     add_slot("gen_vision_model.post_quant_conv.bias", pq_b, K_F32, cfg.vq_z);
+    slot_shape("gen_vision_model.quantize.embedding.weight", {V, Dm}); slot_shape("gen_vision_model.post_quant_conv.weight", {cfg.vq_z, Dm, 1, 1});
     TRY(build_vq());
     if (cfg.with_vision) TRY(build_vision());
 
@@ -414,7 +437,7 @@ int pg_engine::create() {
     slots = cfg.max_prompt + cfg.max_new;
     max_pos = 2 * cfg.max_prompt + cfg.max_new + 64;
     max_tok = (long)cfg.max_rows * cfg.max_prompt;
-    TRY(dalloc(&kv, (size_t)cfg.n_layers * 2 * kv_layer_elems() * esz));
+    TRY(dalloc(&kv, (size_t)cfg.n_layers * 2 * kv_layer_elems() * esz, false));
     TRY(dalloc(&cos_t, (size_t)max_pos * 64 * 4));
     TRY(dalloc(&sin_t, (size_t)max_pos * 64 * 4));
     TRY(dalloc(&zeros, 1024));
@@ -430,10 +453,21 @@ int pg_engine::create() {
     TRY(dalloc(&cfg_pv, (size_t)cfg.max_rows * 16 * 4));
     TRY(dalloc(&cfg_pi, (size_t)cfg.max_rows * 16 * 4));
     HIPCHK(hipMemset(d_ndec, 0, 64));
+    TRY(dalloc(&d_sparams, 64)); TRY(dalloc(&d_tparams, 64));
+    {
+        const size_t nt = (size_t)cfg.max_rows * (cfg.max_new + 1);     // [B, T] with B <= max_rows / 2 ... [R, max_new] for text
+        TRY(dalloc(&d_out_tok, nt * 4)); TRY(dalloc(&d_force_tok, nt * 4)); TRY(dalloc(&d_force_mask, nt));
+        if (cfg.with_lm_head) TRY(dalloc(&d_text_out, nt * 8));
+    }
     TRY(dalloc(&d_tok_row, (size_t)max_tok * 4));
     TRY(dalloc(&d_tok_j, (size_t)max_tok * 4));
     TRY(dalloc(&d_tok_src, (size_t)max_tok * 4));
-    HIPCHK(hipHostMalloc((void**)&h_stage, (size_t)(3 * max_tok + 4 * cfg.max_rows + 16) * 4));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipHostMalloc((void**)&h_stage2[i], (size_t)(3 * max_tok + 5 * cfg.max_rows + 16) * 4));
+        HIPCHK(hipEventCreateWithFlags(&ev_stage[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipHostMalloc((void**)&h_flag, 64));
+    TRY(dalloc(&d_flag, 64));
     TRY(dalloc(&x, (size_t)max_tok * Hh * 4));
     TRY(dalloc(&xn, (size_t)max_tok * Hh * esz));
     long pn = 3L * HDm; if (2L * I > pn) pn = 2L * I; if (Hh > pn) pn = Hh;
@@ -510,7 +544,8 @@ void pg_engine::destroy() {
     drop_graphs();
     for (void* p : allocs) (void)hipFree(p);
     if (stage_dev) (void)hipFree(stage_dev);
-    if (h_stage) (void)hipHostFree(h_stage);
+    for (int i = 0; i < 2; ++i) { if (h_stage2[i]) (void)hipHostFree(h_stage2[i]); if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]); }
+    if (h_flag) (void)hipHostFree(h_flag);
     for (hipEvent_t e : attn_ev) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {ev_in, ev_out, ev_t0, ev_t1, ev_p0, ev_p1, ev_v0, ev_v1, ev_fork, ev_join};
     if (istream2) (void)hipStreamDestroy(istream2);
@@ -527,6 +562,16 @@ int pg_engine::load_tensor(const char* name_c, const void* src, int dtype, const
     Slot& sl = it->second;
     long n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i];
     if (n != sl.n) FAIL(PG_ERR_ARG, "tensor '%s': %ld elements, expected %ld", name.c_str(), n, sl.n);
+    if (!sl.shape.empty() && ndim >= 2) {     // 2-D / 4-D slots: a transposed or re-laid-out tensor has the right count and the wrong shape
+        bool ok = ndim == (int)sl.shape.size();
+        for (int i = 0; ok && i < ndim; ++i) ok = shape[i] == sl.shape[i];
+        if (!ok) {
+            std::string got, want;
+            for (int i = 0; i < ndim; ++i) got += (i ? "," : "") + std::to_string(shape[i]);
+            for (size_t i = 0; i < sl.shape.size(); ++i) want += (i ? "," : "") + std::to_string(sl.shape[i]);
+            FAIL(PG_ERR_ARG, "tensor '%s': shape [%s], expected [%s]", name.c_str(), got.c_str(), want.c_str());
+        }
+    }
     if (dtype != PG_F32 && dtype != PG_BF16) FAIL(PG_ERR_ARG, "tensor '%s': dtype must be f32/bf16", name.c_str());
     HIPCHK(hipSetDevice(dev));
     const long nbytes = n * (dtype == PG_BF16 ? 2 : 4);
@@ -619,7 +664,8 @@ int pg_engine::finalize(int* missing, hipStream_t s) {
         HIPCHK(hipStreamSynchronize(s));
     }
     HIPCHK(hipGetLastError());
-    finalized = true;
+    // missing tensors: the engine refuses to run (prefill / decode / VQ check ``finalized``) unless the caller opted in
+    finalized = miss == 0 || allow_partial;
     return PG_OK;
 }
 int pg_engine::tile_one(hipStream_t s, const void* src, void** dst, int N, int K) {
@@ -724,35 +770,43 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     if (L_ + cfg.max_new + 1 > max_pos) FAIL(PG_ERR_CAPACITY, "padded length %d too long for the RoPE table (%d)", L_, max_pos);
     if (!ids_dev && !emb_dev) FAIL(PG_ERR_ARG, "ids or embeds required");
     HIPCHK(hipSetDevice(dev));
+    for (int r = 0; r < R_; ++r) {                 // validate every row BEFORE pad_len is used as an offset anywhere
+        const int pad = pad_len[r];
+        if (pad < 0 || pad >= L_) FAIL(PG_ERR_ARG, "row %d: pad_len %d not in [0,%d)", r, pad, L_);
+        if (L_ - pad > cfg.max_prompt) FAIL(PG_ERR_CAPACITY, "row %d: %d prompt tokens > max_prompt %d", r, L_ - pad, cfg.max_prompt);
+    }
     // Shared negative prompt (the uncond prompt is batch-constant for non-edit
-    // data): when every odd row carries the same ids and padding, its prompt is prefetched and
-    // its K/V stored ONCE (row 1); the other uncond rows alias it.  Verified on the host, never
-    // assumed; only on the fused path (no per-position hidden output requested).
+    // data): when every odd row carries the same ids and padding, its prompt is prefilled and
+    // its K/V stored ONCE (row 1); the other uncond rows alias it.  Verified per batch, never
+    // assumed: the ids are compared ON THE DEVICE and one 4-byte flag comes back (the only
+    // host<->device round trip of pg_prefill: the packed-token count, hence every GEMM shape of
+    // the prefill, depends on the answer).  Only on the fused path (no per-position hidden output).
     shared_len = 0;
     if (share_uncond && fuse_rope && ids_dev && !hidden_out && pmode == 0 && R_ >= 4 && (R_ % 2) == 0) {
         bool same = true;
         for (int r = 3; r < R_ && same; r += 2) same = pad_len[r] == pad_len[1];
-        if (same && pad_len[1] < L_) {
-            std::vector<int32_t> hid((size_t)(R_ / 2) * L_);
-            HIPCHK(hipMemcpy2DAsync(hid.data(), (size_t)L_ * 4, ids_dev + L_, (size_t)2 * L_ * 4, (size_t)L_ * 4, R_ / 2,
-                                    hipMemcpyDeviceToHost, s));
+        if (same) {
+            HIPCHK(hipMemsetAsync(d_flag, 0, 4, s));
+            launch_rows_differ(s, ids_dev, L_, /*first*/ 3, /*stride*/ 2, /*ref row*/ 1, (R_ - 2) / 2, pad_len[1], d_flag);
+            HIPCHK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            const int p1 = pad_len[1];
-            for (int r = 1; r < R_ / 2 && same; ++r)
-                same = memcmp(hid.data() + (size_t)r * L_ + p1, hid.data() + p1, (size_t)(L_ - p1) * 4) == 0;
-            if (same) shared_len = L_ - p1;
+            if (*h_flag == 0) shared_len = L_ - pad_len[1];
         }
     }
+    // pinned staging is double-buffered: the copies of call n are still in flight while call n+1 fills
+    // the other buffer; a buffer is reused only after the event recorded behind its copies has fired
+    // (two calls back: in practice never waits), so pg_prefill itself does not synchronise the stream.
+    stage_sel ^= 1;
+    int32_t* const hs = h_stage2[stage_sel];
+    if (stage_used[stage_sel]) HIPCHK(hipEventSynchronize(ev_stage[stage_sel]));
     int ntok = 0;
     h_len.assign(R_, 0);
-    int32_t* s_len = h_stage; int32_t* s_off = h_stage + cfg.max_rows; int32_t* s_last = h_stage + 2 * cfg.max_rows;
-    int32_t* s_roff = h_stage + 3 * cfg.max_rows; max_len_host = 0;
-    int32_t* s_row = h_stage + 4 * cfg.max_rows; int32_t* s_j = s_row + max_tok; int32_t* s_src = s_j + max_tok;
+    int32_t* s_len = hs; int32_t* s_off = hs + cfg.max_rows; int32_t* s_last = hs + 2 * cfg.max_rows;
+    int32_t* s_roff = hs + 3 * cfg.max_rows; int32_t* s_ord = hs + 4 * cfg.max_rows; max_len_host = 0;
+    int32_t* s_row = hs + 5 * cfg.max_rows; int32_t* s_j = s_row + max_tok; int32_t* s_src = s_j + max_tok;
     for (int r = 0; r < R_; ++r) {
         const int pad = pad_len[r];
-        if (pad < 0 || pad >= L_) FAIL(PG_ERR_ARG, "row %d: pad_len %d not in [0,%d)", r, pad, L_);
         const int len = L_ - pad;
-        if (len > cfg.max_prompt) FAIL(PG_ERR_CAPACITY, "row %d: %d prompt tokens > max_prompt %d", r, len, cfg.max_prompt);
         h_len[r] = len; s_len[r] = len; s_off[r] = pmode == 0 ? pad : 0;
         if (shared_len > 0 && (r & 1) && r != 1) { s_last[r] = s_last[1]; s_roff[r] = -1; continue; }   // aliases row 1's prompt
         s_roff[r] = ntok; if (len > max_len_host) max_len_host = len;
@@ -761,16 +815,14 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     }
     R = R_; L = L_; Ntok = ntok; pos_mode = pmode; n_dec_host = 0;
     {   // longest-first row order for the decode attention launch (private keys per row)
-        std::vector<int32_t> ord(R_);
-        for (int r = 0; r < R_; ++r) ord[r] = r;
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+        for (int r = 0; r < R_; ++r) s_ord[r] = r;
+        std::stable_sort(s_ord, s_ord + R_, [&](int a, int b) {
             const int ka = h_len[a] - ((shared_len > 0 && (a & 1)) ? shared_len : 0), kb = h_len[b] - ((shared_len > 0 && (b & 1)) ? shared_len : 0);
             return ka > kb; });
-        HIPCHK(hipMemcpyAsync(d_row_order, ord.data(), (size_t)R_ * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
         order_valid = true; order_rows = R_;
     }
     HIPCHK(hipEventRecord(ev_p0, s));
+    HIPCHK(hipMemcpyAsync(d_row_order, s_ord, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_len, s_len, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_pos_off, s_off, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_last, s_last, (size_t)R * 4, hipMemcpyHostToDevice, s));
@@ -778,10 +830,10 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     HIPCHK(hipMemcpyAsync(d_tok_row, s_row, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_tok_j, s_j, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(d_tok_src, s_src, (size_t)ntok * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(ev_stage[stage_sel], s));
+    stage_used[stage_sel] = true;
     HIPCHK(hipMemsetAsync(d_ndec, 0, 64, s));
     HIPCHK(hipMemsetAsync(d_ndec2, 0, 64, s));
-    // the pinned staging buffer is reused by the next call: wait for the copies
-    HIPCHK(hipStreamSynchronize(s));
     if (ids_dev) launch_embed_gather(s, embed, ids_dev, d_tok_src, x, ntok, H(), cfg.vocab);
     else launch_rows_to_f32(s, emb_dev, emb_dtype == PG_BF16, d_tok_src, x, ntok, H());
     if (bf) run_layers<bf16>(s, ntok, 1, (bf16*)xn); else run_layers<float>(s, ntok, 1, (float*)xn);
@@ -853,9 +905,10 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
         x = x0; xn = xn0; qbuf = q0; obuf = o0; hbuf = hb0; hfin = hf0; gh_mid = gm0; part = p0; d_len = len0; d_pos_off = po0;
         d_ndec = nd0; cfg_pv = pv0; cfg_pi = pi0; kv_row_off = 0; shared_row = 1; h_len_off = 0; R = Rtot;
     };
+    if (force_mask && !force_tok) FAIL(PG_ERR_ARG, "force_mask needs force_tok");
     SampleArgs sa{};
-    sa.bias = gh_b2; sa.V = cfg.img_vocab; sa.cfg_weight = cfgw; sa.temperature = temp; sa.seed = seed;
-    sa.force_tok = force_tok; sa.force_mask = force_mask; sa.T = T; sa.out_tok = out_tok; sa.logits_out = logits_out;
+    sa.bias = gh_b2; sa.V = cfg.img_vocab; sa.p = d_sparams;
+    sa.force_tok = d_force_tok; sa.force_mask = d_force_mask; sa.out_tok = d_out_tok; sa.logits_out = logits_out;
     sa.embed_table = gen_table; sa.H = Hh; sa.B_total = B;
     auto sample = [&](hipStream_t st, const LaneDef& L) {
         if (bf) head_logits<bf16>(st, (const bf16*)hfin, R); else head_logits<float>(st, (const float*)hfin, R);
@@ -890,15 +943,22 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
         return PG_OK;
     };
     HIPCHK(hipEventRecord(ev_t0, ws));
+    {   // per-call parameters and the caller's forcing tensors -> library-owned device memory (what the graph reads)
+        SampleParams sp{}; sp.cfg_weight = cfgw; sp.temperature = temp; sp.seed = seed; sp.T = T;
+        sp.has_force = force_tok != nullptr; sp.has_mask = force_mask != nullptr;
+        launch_set_sample_params(ws, d_sparams, sp);
+        if (force_tok) HIPCHK(hipMemcpyAsync(d_force_tok, force_tok, (size_t)B * T * 4, hipMemcpyDeviceToDevice, ws));
+        if (force_mask) HIPCHK(hipMemcpyAsync(d_force_mask, force_mask, (size_t)B * T, hipMemcpyDeviceToDevice, ws));
+    }
     if (free_lanes) { HIPCHK(hipEventRecord(ev_fork, ws)); HIPCHK(hipStreamWaitEvent(istream2, ev_fork, 0)); }
     TRY(iteration(T > 1));
     if (T > 1) n_dec_host++;
     int i = 1;
     if (graph) {
-        std::vector<int64_t> key = {Rtot, T, (int64_t)bf, (int64_t)__builtin_bit_cast(int32_t, cfgw),
-                                    (int64_t)__builtin_bit_cast(int32_t, temp), (int64_t)seed, (int64_t)force_tok,
-                                    (int64_t)force_mask, (int64_t)out_tok, (int64_t)logits_out, (int64_t)shared_len, (int64_t)fuse_rope,
-                                    (int64_t)nl};
+        // shapes and kernel selection only: seeds, temperatures, T and the caller's buffers reach the kernels through
+        // device memory, so a bench / serving loop replays ONE instantiated graph across calls
+        std::vector<int64_t> key = {Rtot, (int64_t)bf, (int64_t)logits_out, (int64_t)shared_len, (int64_t)fuse_rope, (int64_t)nl,
+                                    (int64_t)(lpt_order && order_valid), (int64_t)tune_epoch};
         if (!gexec || key != gkey) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
             hipGraph_t g = nullptr;
@@ -917,6 +977,7 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     }
     if (T > 1) TRY(iteration(false));
     if (free_lanes) { HIPCHK(hipEventRecord(ev_join, istream2)); HIPCHK(hipStreamWaitEvent(ws, ev_join, 0)); }
+    HIPCHK(hipMemcpyAsync(out_tok, d_out_tok, (size_t)B * T * 4, hipMemcpyDeviceToDevice, ws));
     HIPCHK(hipEventRecord(ev_t1, ws));
     if (ws != s) {
         HIPCHK(hipEventRecord(ev_out, ws));
@@ -972,7 +1033,7 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
     HIPCHK(hipMemsetAsync(d_anyunf, 0, 1024 * 4, s));
     HIPCHK(hipStreamSynchronize(s));
     TextArgs ta{};
-    ta.V = cfg.vocab; ta.eos = eos; ta.min_new = min_new; ta.out = out; ta.max_new = max_new; ta.unfinished = d_unf;
+    ta.V = cfg.vocab; ta.p = d_tparams; ta.out = d_text_out; ta.unfinished = d_unf;
     ta.any_unfinished = d_anyunf; ta.embed_table = embed; ta.x = x; ta.H = H(); ta.n_dec = d_ndec;
     std::vector<int32_t> flags(1024);
     int checked = 0, done_len = -1;
@@ -985,6 +1046,7 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
         HIPCHK(hipStreamWaitEvent(istream, ev_in, 0));
         ws = istream;
     }
+    { TextParams tp{}; tp.eos = eos; tp.min_new = min_new; tp.max_new = max_new; launch_set_text_params(ws, d_tparams, tp); }
     auto iteration = [&](bool with_forward) {
         if (bf) gemm_llm<bf16>(ws, (const bf16*)hfin, (const bf16*)lm_head, B, cfg.vocab, H(), true, lm_head_t);
         else gemm_llm<float>(ws, (const float*)hfin, (const float*)lm_head, B, cfg.vocab, H(), true);
@@ -995,7 +1057,7 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
     for (int step_i = 0; step_i < max_new; ++step_i) {
         const bool last = step_i == max_new - 1;
         if (use_graph && !last && step_i > 0) {
-            std::vector<int64_t> key = {R, (int64_t)bf, eos, min_new, max_new, (int64_t)out, (int64_t)fuse_rope, (int64_t)shared_len};
+            std::vector<int64_t> key = {R, (int64_t)bf, (int64_t)fuse_rope, (int64_t)shared_len, (int64_t)(lpt_order && order_valid), (int64_t)tune_epoch};
             if (!gexec_txt || key != gkey_txt) {
                 if (gexec_txt) { (void)hipGraphExecDestroy(gexec_txt); gexec_txt = nullptr; }
                 hipGraph_t g = nullptr;
@@ -1019,11 +1081,13 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
             if (done_len >= 0) break;
         }
     }
+    if (done_len < 0) done_len = max_new;
+    // only the columns this call produced; the caller's buffer keeps its own fill beyond them
+    HIPCHK(hipMemcpy2DAsync(out, (size_t)max_new * 8, d_text_out, (size_t)max_new * 8, (size_t)done_len * 8, B, hipMemcpyDeviceToDevice, ws));
     if (ws != s) {
         HIPCHK(hipEventRecord(ev_out, ws));
         HIPCHK(hipStreamWaitEvent(s, ev_out, 0));
     }
-    if (done_len < 0) done_len = max_new;
     if (out_len) *out_len = done_len;
     HIPCHK(hipGetLastError());
     return PG_OK;
@@ -1267,6 +1331,12 @@ int pg_engine::fetch_timing() {
 }
 
 // =============================================================================== C ABI
+struct TuneGuard {          // points this thread's kernel launchers at the handle's knobs for the duration of one ABI call
+    const PgTune* saved;
+    explicit TuneGuard(pg_handle h) : saved(pg_tune) { if (h) pg_tune = &h->tune; }
+    ~TuneGuard() { pg_tune = saved; }
+};
+
 extern "C" {
 
 int pg_create(pg_handle* out, const pg_config* cfg, int device_id) {
@@ -1285,29 +1355,30 @@ int pg_load_tensor(pg_handle h, const char* name, const void* src, int dtype, co
     if (!h || !name || !src) return PG_ERR_ARG;
     return h->load_tensor(name, src, dtype, shape, ndim);
 }
-int pg_finalize_weights(pg_handle h, int* missing, pg_stream s) { return h ? h->finalize(missing, (hipStream_t)s) : PG_ERR_ARG; }
+int pg_finalize_weights(pg_handle h, int* missing, pg_stream s) { TuneGuard _tg(h); return h ? h->finalize(missing, (hipStream_t)s) : PG_ERR_ARG; }
 
 int pg_prefill(pg_handle h, const int32_t* ids_dev, const int32_t* pad_len_host, int R, int L, int position_mode,
-               void* hidden_out_dev, int hidden_dtype, pg_stream s) {
+               void* hidden_out_dev, int hidden_dtype, pg_stream s) { TuneGuard _tg(h);
     if (!h || !ids_dev || !pad_len_host) return PG_ERR_ARG;
     return h->prefill(ids_dev, nullptr, 0, pad_len_host, R, L, position_mode, hidden_out_dev, hidden_dtype, (hipStream_t)s);
 }
 int pg_prefill_embeds(pg_handle h, const void* embeds_dev, int embeds_dtype, const int32_t* pad_len_host, int R, int L,
-                      int position_mode, void* hidden_out_dev, int hidden_dtype, pg_stream s) {
+                      int position_mode, void* hidden_out_dev, int hidden_dtype, pg_stream s) { TuneGuard _tg(h);
     if (!h || !embeds_dev || !pad_len_host) return PG_ERR_ARG;
     return h->prefill(nullptr, embeds_dev, embeds_dtype, pad_len_host, R, L, position_mode, hidden_out_dev, hidden_dtype, (hipStream_t)s);
 }
-int pg_step(pg_handle h, const void* embeds_dev, int embeds_dtype, void* hidden_out_dev, int hidden_dtype, pg_stream s) {
+int pg_step(pg_handle h, const void* embeds_dev, int embeds_dtype, void* hidden_out_dev, int hidden_dtype, pg_stream s) { TuneGuard _tg(h);
     if (!h || !embeds_dev) return PG_ERR_ARG;
     return h->step(embeds_dev, embeds_dtype, hidden_out_dev, hidden_dtype, (hipStream_t)s);
 }
-int pg_gen_head(pg_handle h, const void* h_dev, int h_dtype, float* logits_dev, int R, pg_stream s) {
+int pg_gen_head(pg_handle h, const void* h_dev, int h_dtype, float* logits_dev, int R, pg_stream s) { TuneGuard _tg(h);
     if (!h || !h_dev || !logits_dev) return PG_ERR_ARG;
     return h->gen_head(h_dev, h_dtype, logits_dev, R, (hipStream_t)s);
 }
 int pg_gen_embed(pg_handle h, const int32_t* tok_dev, void* out_dev, int out_dtype, int R, pg_stream s) {
     if (!h || !tok_dev || !out_dev) return PG_ERR_ARG;
     if (!h->finalized) { h->err = "pg_finalize_weights not called"; return PG_ERR_STATE; }
+    if (R < 0 || (out_dtype != PG_F32 && (long)R * h->H() > h->part_elems)) { h->err = "pg_gen_embed: too many rows for the bf16 output scratch"; return PG_ERR_CAPACITY; }
     (void)hipSetDevice(h->dev);
     hipStream_t st = (hipStream_t)s;
     if (out_dtype == PG_F32) launch_embed_gather(st, h->gen_table, tok_dev, nullptr, (float*)out_dev, R, h->H(), h->cfg.img_vocab);
@@ -1332,25 +1403,25 @@ int pg_embed_tokens(pg_handle h, const int32_t* ids_dev, void* out_dev, int out_
 }
 int pg_decode_image_tokens(pg_handle h, int T, float cfg_weight, float temperature, uint64_t seed,
                            const int32_t* force_tok_dev, const uint8_t* force_mask_dev, int32_t* out_tok_dev,
-                           float* logits_out_dev, pg_stream s) {
+                           float* logits_out_dev, pg_stream s) { TuneGuard _tg(h);
     if (!h || !out_tok_dev) return PG_ERR_ARG;
     return h->decode_image(T, cfg_weight, temperature, seed, force_tok_dev, force_mask_dev, out_tok_dev, logits_out_dev, (hipStream_t)s);
 }
-int pg_generate_text_greedy(pg_handle h, int max_new, int min_new, int eos_id, int64_t* out_dev, int* out_len_host, pg_stream s) {
+int pg_generate_text_greedy(pg_handle h, int max_new, int min_new, int eos_id, int64_t* out_dev, int* out_len_host, pg_stream s) { TuneGuard _tg(h);
     if (!h || !out_dev) return PG_ERR_ARG;
     return h->text_greedy(max_new, min_new, eos_id, out_dev, out_len_host, (hipStream_t)s);
 }
-int pg_vq_decode(pg_handle h, const int32_t* codes_dev, void* img_out_dev, int out_dtype, int B, pg_stream s) {
+int pg_vq_decode(pg_handle h, const int32_t* codes_dev, void* img_out_dev, int out_dtype, int B, pg_stream s) { TuneGuard _tg(h);
     if (!h || !codes_dev || !img_out_dev) return PG_ERR_ARG;
     return h->bf ? h->vq_decode<bf16>(codes_dev, img_out_dev, out_dtype, B, (hipStream_t)s)
                  : h->vq_decode<float>(codes_dev, img_out_dev, out_dtype, B, (hipStream_t)s);
 }
-int pg_vq_encode(pg_handle h, const void* img_dev, int img_dtype, int64_t* idx_out_dev, int B, pg_stream s) {
+int pg_vq_encode(pg_handle h, const void* img_dev, int img_dtype, int64_t* idx_out_dev, int B, pg_stream s) { TuneGuard _tg(h);
     if (!h || !img_dev || !idx_out_dev) return PG_ERR_ARG;
     return h->bf ? h->vq_encode<bf16>(img_dev, img_dtype, idx_out_dev, B, (hipStream_t)s)
                  : h->vq_encode<float>(img_dev, img_dtype, idx_out_dev, B, (hipStream_t)s);
 }
-int pg_vision_encode(pg_handle h, const void* img_dev, int img_dtype, void* out_dev, int out_dtype, int B, pg_stream s) {
+int pg_vision_encode(pg_handle h, const void* img_dev, int img_dtype, void* out_dev, int out_dtype, int B, pg_stream s) { TuneGuard _tg(h);
     if (!h || !img_dev || !out_dev) return PG_ERR_ARG;
     return h->bf ? h->vision_encode<bf16>(img_dev, img_dtype, out_dev, out_dtype, B, (hipStream_t)s)
                  : h->vision_encode<float>(img_dev, img_dtype, out_dev, out_dtype, B, (hipStream_t)s);
@@ -1364,18 +1435,19 @@ int pg_get_timing(pg_handle h, pg_timing* out) {
 int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!h || !key) return PG_ERR_ARG;
     if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
+    if (!strcmp(key, "allow_partial_weights")) { h->allow_partial = value != 0; return PG_OK; }
     if (!strncmp(key, "split_target_", 13)) {
-        extern int g_split_target_small, g_split_target_mid, g_split_target_big;
-        (key[13] == 's' ? g_split_target_small : key[13] == 'm' ? g_split_target_mid : g_split_target_big) = (int)value;
-        h->drop_graphs(); return PG_OK;
+        (key[13] == 's' ? h->tune.split_small : key[13] == 'm' ? h->tune.split_mid : h->tune.split_big) = (int)value;
+        h->tune_epoch++; return PG_OK;
     }
-    if (!strcmp(key, "force_swiglu")) { h->force_swiglu = value != 0; h->drop_graphs(); return PG_OK; }
+    if (!strcmp(key, "force_swiglu")) { h->force_swiglu = value != 0; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
     if (!strcmp(key, "share_uncond")) { h->share_uncond = value != 0; return PG_OK; }
     if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
     if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
-    if (!strcmp(key, "gemm256")) { g_gemm256 = (int)value; return PG_OK; }
-    if (!strcmp(key, "conv_halo")) { g_conv_halo = (int)value; return PG_OK; }
+    if (!strcmp(key, "gemm256")) { h->tune.gemm256 = (int)value; return PG_OK; }
+    if (!strcmp(key, "conv_halo")) { h->tune.conv_halo = (int)value; return PG_OK; }
+    if (!strcmp(key, "stream_gemm")) { h->tune.stream_gemm = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "cu_split")) {
         // lane streams with complementary CU masks: 1 = low / high half of the mask bits, 2 = even / odd bits,
         // 3 = alternating groups of 32 bits, 4 = alternating groups of 8 bits; 0 = unmasked streams
@@ -1403,10 +1475,10 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
         return PG_OK;
     }
     if (!strcmp(key, "gn_fuse")) { h->gn_fuse = value != 0; return PG_OK; }
-    if (!strcmp(key, "attn_waves")) { g_attn_waves = (int)value; h->drop_graphs(); return PG_OK; }
-    if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; h->drop_graphs(); return PG_OK; }
-    if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->drop_graphs(); return PG_OK; }
-    if (!strcmp(key, "attn_variant")) { extern int g_attn_variant; g_attn_variant = (int)value; h->drop_graphs(); return PG_OK; }
+    if (!strcmp(key, "attn_waves")) { h->tune.attn_waves = (int)value; h->tune_epoch++; return PG_OK; }
+    if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; h->tune_epoch++; return PG_OK; }
+    if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->tune_epoch++; return PG_OK; }
+    if (!strcmp(key, "attn_variant")) { h->tune.attn_variant = (int)value; h->tune_epoch++; return PG_OK; }
     h->err = std::string("unknown option ") + key;
     return PG_ERR_ARG;
 }
@@ -1433,7 +1505,7 @@ int pg_debug_read(pg_handle h, const char* name, int index, void* dst_dev, int64
 }
 
 int pg_op_rmsnorm(pg_handle h, float* x_dev, const float* partial_dev, int S, const void* w_dev, void* out_dev, int M, int H,
-                  float eps, pg_stream s) {
+                  float eps, pg_stream s) { TuneGuard _tg(h);
     if (!h || !x_dev || !w_dev) return PG_ERR_ARG;
     (void)hipSetDevice(h->dev);
     if (h->bf) launch_rmsnorm<bf16>((hipStream_t)s, x_dev, partial_dev, S, (long)M * H, (const bf16*)w_dev, (bf16*)out_dev, M, H, eps);
@@ -1441,13 +1513,20 @@ int pg_op_rmsnorm(pg_handle h, float* x_dev, const float* partial_dev, int S, co
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
 }
 int pg_op_gemm(pg_handle h, const void* a_dev, const void* w_dev, float* out_dev, int M, int N, int K, int force_kind,
-               int* S_out, pg_stream s) {
+               int* S_out, pg_stream s) { TuneGuard _tg(h);
     if (!h || !a_dev || !w_dev || !out_dev) return PG_ERR_ARG;
     (void)hipSetDevice(h->dev);
     int S = 1;
-    if (h->bf && (force_kind == 1 || (force_kind == 0 && M <= 128)) && K % 128 == 0) {
+    if (h->bf && (force_kind == 1 || force_kind == 4 || (force_kind == 0 && M <= 128)) && K % 128 == 0) {
         S = skinny_pick_splits(N, K, M);
-        launch_gemm_skinny((hipStream_t)s, (const bf16*)a_dev, (const bf16*)w_dev, out_dev, M, N, K, S);
+        bf16* wt = nullptr;
+        if (force_kind == 4) {     // the decode layout: tiled copy of W built exactly like pg_finalize_weights does
+            if ((N & 15)) { h->err = "pg_op_gemm: tiled mode needs N % 16 == 0"; return PG_ERR_ARG; }
+            if (hipMalloc((void**)&wt, (size_t)N * K * 2) != hipSuccess) { h->err = "pg_op_gemm: hipMalloc failed"; return PG_ERR_HIP; }
+            launch_tile_weights((hipStream_t)s, (const bf16*)w_dev, wt, N, K);
+        }
+        launch_gemm_skinny((hipStream_t)s, (const bf16*)a_dev, (const bf16*)w_dev, out_dev, M, N, K, S, wt);
+        if (wt) { (void)hipStreamSynchronize((hipStream_t)s); (void)hipFree(wt); }
     } else {
         GemmA ga; ga.ptr = a_dev; ga.lda = K;
         GemmEpi e; e.out = out_dev; e.out_f32 = 1; e.ldc = N;
@@ -1457,8 +1536,27 @@ int pg_op_gemm(pg_handle h, const void* a_dev, const void* w_dev, float* out_dev
     if (S_out) *S_out = S;
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
 }
+int pg_op_swiglu_gemm(pg_handle h, const void* a_dev, const void* wgu_dev, void* h_out_dev, int M, int I, int K, pg_stream s) { TuneGuard _tg(h);
+    if (!h || !a_dev || !wgu_dev || !h_out_dev) return PG_ERR_ARG;
+    if (!h->bf || K % 128 || (I & 7)) { h->err = "pg_op_swiglu_gemm: bf16 engine, K % 128 == 0, I % 8 == 0"; return PG_ERR_ARG; }
+    (void)hipSetDevice(h->dev);
+    bf16* wt = nullptr;
+    if (hipMalloc((void**)&wt, (size_t)2 * I * K * 2) != hipSuccess) { h->err = "pg_op_swiglu_gemm: hipMalloc failed"; return PG_ERR_HIP; }
+    launch_tile_weights((hipStream_t)s, (const bf16*)wgu_dev, wt, 2 * I, K);
+    const bool ok = launch_gemm_skinny_swiglu((hipStream_t)s, (const bf16*)a_dev, (const bf16*)wgu_dev, (bf16*)h_out_dev, M, 2 * I, K, wt);
+    (void)hipStreamSynchronize((hipStream_t)s);
+    (void)hipFree(wt);
+    if (!ok) { h->err = "pg_op_swiglu_gemm: no fused instantiation for this shape"; return PG_ERR_ARG; }
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
+int pg_op_uniform(pg_handle h, const uint64_t* bits_dev, float* out_dev, int n, pg_stream s) {
+    if (!h || !bits_dev || !out_dev) return PG_ERR_ARG;
+    (void)hipSetDevice(h->dev);
+    launch_uniform_from_bits((hipStream_t)s, bits_dev, out_dev, n);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
 int pg_op_conv3x3(pg_handle h, const void* x_dev, const void* w_dev, const float* bias_dev, const void* residual_dev,
-                  void* out_dev, int B, int Hi, int Wi, int Cin, int Cout, int up, int stride2, pg_stream s) {
+                  void* out_dev, int B, int Hi, int Wi, int Cin, int Cout, int up, int stride2, pg_stream s) { TuneGuard _tg(h);
     if (!h || !x_dev || !w_dev || !out_dev) return PG_ERR_ARG;
     (void)hipSetDevice(h->dev);
     ConvW cw; cw.w = (void*)w_dev; cw.b = (float*)bias_dev; cw.cin = Cin; cw.cout = Cout;
@@ -1467,7 +1565,7 @@ int pg_op_conv3x3(pg_handle h, const void* x_dev, const void* w_dev, const float
     return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
 }
 int pg_op_groupnorm(pg_handle h, const void* x_dev, const float* gamma_dev, const float* beta_dev, void* out_dev, int B,
-                    int HW, int C, int swish, pg_stream s) {
+                    int HW, int C, int swish, pg_stream s) { TuneGuard _tg(h);
     if (!h || !x_dev || !out_dev) return PG_ERR_ARG;
     if (B > h->cfg.max_images || C > 1024) { h->err = "pg_op_groupnorm: B > max_images or C > 1024"; return PG_ERR_CAPACITY; }
     (void)hipSetDevice(h->dev);

@@ -167,7 +167,7 @@ template <typename T> struct BigDispatch;
 template <> struct BigDispatch<bf16> {
     static void run(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e,
                     int M, int N, int K, int batch, int batch2, long strideB2) {
-        if (batch == 1 && batch2 == 1 && g_gemm256 && conv_halo_try(s, a, W, e, M, N, K, (float*)a.gn_part, a.gn_nsplit)) return;
+        if (batch == 1 && batch2 == 1 && pg_tune->gemm256 && conv_halo_try(s, a, W, e, M, N, K, (float*)a.gn_part, a.gn_nsplit)) return;
         if (gemm256_try(s, a, W, ldb, strideB, e, M, N, K, batch, batch2, strideB2)) return;
         Epi<bf16> ep{e, M, N};
         const int ntm = (M + BIG_BM - 1) / BIG_BM, ntn = (N + BIG_BN - 1) / BIG_BN;
@@ -376,11 +376,11 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16* __restr
 // 256 CUs streaming.  Measured on MI355X (tools/skinny_sweep.py): at M = 128 fewer, fatter
 // blocks win (slab traffic grows with S), at M <= 32 more, thinner ones do; S is restricted to
 // chunk counts the unrolled kernel is instantiated for.
-int g_split_target_small = 128;   // pg_set_option("split_target_{small,mid,big}", n): block-count targets at M < 48 / < 96 / >= 96
-int g_split_target_mid = 256, g_split_target_big = 128;
+static const PgTune g_default_tune{};
+thread_local const PgTune* pg_tune = &g_default_tune;
 int skinny_pick_splits(int N, int K, int M) {
     const int nblk = (N + 63) / 64, nchunks = K / SK_BK;
-    const int target = M >= 96 ? g_split_target_big : (M >= 48 ? g_split_target_mid : g_split_target_small);   // GEMM+consumer optimum (sweep "+n" columns)
+    const int target = M >= 96 ? pg_tune->split_big : (M >= 48 ? pg_tune->split_mid : pg_tune->split_small);   // GEMM+consumer optimum (sweep "+n" columns)
     int best = 1;
     for (int S = 1; S <= nchunks; ++S) {
         if (nchunks % S) continue;

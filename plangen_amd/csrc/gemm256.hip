@@ -240,7 +240,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // clamped tail stages must not outlive the block's LDS
 }
 
-int g_gemm256 = 1;          // pg_set_option("gemm256", 0/1): 0 = 128x128 kernel everywhere
 
 template <class AL, int WM, int WN>
 static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long strideA, long strideB, long strideA2, long strideB2,
@@ -258,7 +257,7 @@ static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long stride
 // Takes the shapes the big tiles fill well; everything else stays on the 128^2 kernel.
 bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e, int M, int N, int K,
                  int batch, int batch2, long strideB2) {
-    if (!g_gemm256 || K % G2_BK || K < 2 * G2_BK) return false;
+    if (!pg_tune->gemm256 || K % G2_BK || K < 2 * G2_BK) return false;
     // (a 4x2-wave 512x128 instantiation for the Cout = 128 convolutions was measured: 470-560 TFLOP/s against
     // 640-690 for the 128x128 kernel -- K = 9*Cin is only 18-36 K tiles, so the fill / drain of one persistent
     // block per CU and the 8-slot im2col address state outweigh the deeper pipeline; not instantiated)

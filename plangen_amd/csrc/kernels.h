@@ -12,6 +12,17 @@
 //         K = 9*Cin ordered (tap, ci); Cin % 64 == 0.
 // kind 2: same with stride 2 and the reference's asymmetric (0,1,0,1) padding
 //         (Downsample, vq_model.py:440-447): Ho = Hi/2.
+// Tuning knobs (pg_set_option) are PER HANDLE: every C-ABI entry point points the calling thread's ``pg_tune``
+// at its handle's copy before it launches anything, so two handles in one process do not interfere.
+struct PgTune {
+    int split_small = 128, split_mid = 256, split_big = 128;   // decode split-K block-count targets at M < 48 / < 96 / >= 96
+    int gemm256 = 1;                                            // 256x256 eight-phase MFMA GEMM for large shapes
+    int conv_halo = 1;                                          // direct halo-tile 3x3 convolution (2: lock-step variant)
+    int attn_waves = 0;                                         // 4 / 8 pin the decode-attention block size
+    int attn_variant = -1;                                      // unfused attention kernel variant (-1: by mode)
+    int stream_gemm = 1;                                        // decode GEMMs on the weight-streaming kernel where it has an instantiation
+};
+extern thread_local const PgTune* pg_tune;
 struct GemmA {
     int kind = 0;
     const void* ptr = nullptr;
@@ -42,7 +53,6 @@ void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strid
 // 256x256 eight-phase kernel (gemm256.hip); returns false when the shape should stay on the 128x128 kernel.
 bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e, int M, int N, int K,
                  int batch, int batch2, long strideB2);
-extern int g_gemm256;
 void launch_attn_vit_flash(hipStream_t s, const bf16* qk, const bf16* vt, bf16* o, int B, int P, int C, int NH, float scale);
 // direct 3x3 convolution with an LDS-resident input halo tile (conv_halo.hip), Cin = Cout = 128
 // gn_part (optional, fp32 output only): per-(image, tile, group) GroupNorm partial sums of the stored tensor,
@@ -51,10 +61,8 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
                    int* gn_nsplit = nullptr);
 void launch_gn_finalize(hipStream_t s, const float* ws, float* stats, float* coef, const float* gamma, const float* beta, int B,
                         int nsplit, int HW, int C, float eps);
-extern int g_conv_halo;
 bool conv_out_halo_try(hipStream_t s, const bf16* x, const bf16* w, const float* bias, const bf16* zeros, void* out, int out_bf16,
                        int B, int H, int Wd, int Cin, int Cout);
-extern int g_attn_waves;
 
 // Skinny weight-streaming GEMM (decode): x [M,K] bf16 (M <= 128 per launch block-row),
 // W [N,K] bf16, out fp32 [S,M,N] split-K partial slabs (consumer kernels reduce over S).
@@ -126,28 +134,39 @@ void launch_bias_act(hipStream_t s, const float* partial, int S, long slab, cons
 // logits fp32 [M,N] = sum_s partial + bias
 void launch_bias_f32(hipStream_t s, const float* partial, int S, long slab, const float* bias, float* out, int M, int N);
 
+// Per-call sampling parameters live in DEVICE memory (written by a 1-thread kernel at the top of
+// pg_decode_image_tokens), so the captured decode-step graph depends on shapes only and is replayed
+// across calls with different seeds / temperatures / caller buffers.
+struct SampleParams { float cfg_weight, temperature; uint64_t seed; int32_t T, has_force, has_mask, pad; };
 struct SampleArgs {
     const float* logits_partial; int S; long slab; const float* bias; int V;
-    float cfg_weight, temperature; uint64_t seed;
-    const int32_t* force_tok; const uint8_t* force_mask; int T;   // [B,T]
-    int32_t* out_tok;                                             // [B,T]
-    float* logits_out;                                            // [T,B,V] or null
+    const SampleParams* p;
+    const int32_t* force_tok; const uint8_t* force_mask;          // [B,T] library-owned copies (valid when p->has_force / has_mask)
+    int32_t* out_tok;                                             // [B,T] library-owned; copied to the caller at the end of the loop
+    float* logits_out;                                            // [T,B,V] or null (tests)
     const float* embed_table;                                     // [V, H] fp32 (gen_embed->gen_aligner)
     float* x; int H;                                              // residual stream rows [2B, H]
     const int32_t* n_dec;
     int b_off, B_total;                                           // this launch covers images [b_off, b_off + gridDim) of B_total
 };
+void launch_set_sample_params(hipStream_t s, SampleParams* dst, SampleParams v);
 // scratch: >= 16*B floats and ints
 void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B, float* scratch_v, int* scratch_i);
 // greedy text: argmax over vocab of (sum_s partial) per row + EOS bookkeeping, writes
 // out[b, step] (int64) and next-token embedding into x.
+struct TextParams { int32_t eos, min_new, max_new, pad; };
 struct TextArgs {
-    const float* logits_partial; int S; long slab; int V; int eos; int min_new;
-    int64_t* out; int max_new; int32_t* unfinished; int32_t* any_unfinished;
+    const float* logits_partial; int S; long slab; int V;
+    const TextParams* p;
+    int64_t* out;                                                 // [B, max_new] library-owned
+    int32_t* unfinished; int32_t* any_unfinished;
     const float* embed_table; float* x; int H; const int32_t* n_dec;
 };
+void launch_set_text_params(hipStream_t s, TextParams* dst, TextParams v);
 void launch_text_argmax(hipStream_t s, const TextArgs& a, int B);
 void launch_advance(hipStream_t s, int32_t* n_dec);
+void launch_rows_differ(hipStream_t s, const int32_t* ids, int L, int first, int stride, int ref, int n, int from, int32_t* flag);
+void launch_uniform_from_bits(hipStream_t s, const uint64_t* z, float* out, int n);
 
 // ---------------------------------------------------------------- VQ
 // NHWC activations of type T.

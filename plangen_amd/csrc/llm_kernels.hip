@@ -117,6 +117,21 @@ void launch_t_to_rows(hipStream_t s, const T* src, void* dst, int dst_bf16, cons
 template void launch_t_to_rows<float>(hipStream_t, const float*, void*, int, const int32_t*, int, int);
 template void launch_t_to_rows<bf16>(hipStream_t, const bf16*, void*, int, const int32_t*, int, int);
 
+// flag |= any(ids[row][from..L) != ids[ref][from..L)) over rows first, first+stride, ... (n rows): the
+// batch-constant negative prompt probe of pg_prefill (plangen_base.py:673-686 builds every uncond row from
+// the same neg_prompt; verified, not assumed).
+__global__ void rows_differ_kernel(const int32_t* __restrict__ ids, int L, int first, int stride, int ref, int from, int32_t* __restrict__ flag) {
+    const int32_t* a = ids + (long)(first + blockIdx.x * stride) * L;
+    const int32_t* b = ids + (long)ref * L;
+    int diff = 0;
+    for (int j = from + threadIdx.x; j < L; j += blockDim.x) diff |= a[j] != b[j];
+    if (diff) atomicOr(flag, 1);
+}
+void launch_rows_differ(hipStream_t s, const int32_t* ids, int L, int first, int stride, int ref, int n, int from, int32_t* flag) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(rows_differ_kernel, dim3(n), dim3(256), 0, s, ids, L, first, stride, ref, from, flag);
+}
+
 // ------------------------------------------------------------------------------- RoPE + KV append
 // grid (M tokens, nh/4), 256 threads = 4 heads x 64 rotation pairs.  rotate_half form
 // (half-split, not interleaved): out[j] = x[j]cos - x[j+64]sin, out[j+64] = x[j+64]cos + x[j]sin.
@@ -397,14 +412,13 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
         ET<T>::st(obuf + (long)row * HD + head * 128 + tid, num / den);
     }
 }
-int g_attn_waves = 0;        // pg_set_option("attn_waves", 4) pins the 4-wave block (A/B)
 template <typename T>
 void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc,
                               const float* cos_t, const float* sin_t, SeqState st, int M, int nh, int slots,
                               int max_pos, float scale) {
     if (M <= 0) return;
     // few (row, head) blocks (small batch): eight waves per block keep 2x the K/V bytes in flight per CU
-    if ((M * nh <= 512 && g_attn_waves != 4) || g_attn_waves == 8)
+    if ((M * nh <= 512 && pg_tune->attn_waves != 4) || pg_tune->attn_waves == 8)
         hipLaunchKernelGGL((attn_decode_fused_kernel<T, 8, 8>), dim3(nh, M), dim3(512), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
                            st, nh, slots, max_pos, scale);
     else
@@ -414,13 +428,12 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
 template void launch_attn_decode_fused<float>(hipStream_t, const float*, int, long, float*, float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
 template void launch_attn_decode_fused<bf16>(hipStream_t, const float*, int, long, bf16*, bf16*, bf16*, const float*, const float*, SeqState, int, int, int, int, float);
 
-int g_attn_variant = -1;      // tuning knob (pg_set_option "attn_variant"); -1: nt loads for decode, plain for prefill
 template <typename T>
 void launch_attn(hipStream_t s, const T* qbuf, T* obuf, const T* kc, const T* vc, SeqState st, int mode,
                  int M, int nh, int slots, float scale) {
     if (M <= 0) return;
     dim3 grid(M, nh), block(256);
-    const int variant = g_attn_variant >= 0 ? g_attn_variant : (mode == 0 ? 1 : 0);
+    const int variant = pg_tune->attn_variant >= 0 ? pg_tune->attn_variant : (mode == 0 ? 1 : 0);
     switch (variant) {
         case 1: hipLaunchKernelGGL((attn_kernel<T, 8, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
         case 2: hipLaunchKernelGGL((attn_kernel<T, 4, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
@@ -498,17 +511,19 @@ __global__ __launch_bounds__(256) void cfg_scan_kernel(SampleArgs a, float* __re
     const int per = (a.V + CFG_CHUNKS - 1) / CFG_CHUNKS, v0 = ch * per, v1 = min(a.V, v0 + per);
     const long rc = (long)(2 * b) * a.V, ru = (long)(2 * b + 1) * a.V;
     float best = -INFINITY; int bi = 0x7fffffff;
-    const float invT = a.temperature > 0.f ? 1.f / a.temperature : 1.f;
+    const float temperature = a.p->temperature, cfg_weight = a.p->cfg_weight;
+    const uint64_t seed = a.p->seed;
+    const float invT = temperature > 0.f ? 1.f / temperature : 1.f;
     for (int v = v0 + tid; v < v1; v += 256) {
         const float b0 = a.bias ? a.bias[v] : 0.f;
         float cu[2] = {b0, b0};
         const int ocu[2] = {0, a.V};                          // cond row, uncond row (adjacent rows)
         sum_slabs<2>(a.logits_partial + rc + v, a.slab, a.S, ocu, cu);
         const float c = cu[0], u = cu[1];
-        float mixed = u + a.cfg_weight * (c - u);
+        float mixed = u + cfg_weight * (c - u);
         if (a.logits_out) a.logits_out[((long)step * B + bg) * a.V + v] = mixed;
-        if (a.temperature > 0.f) {
-            const float uu = rng_uniform(a.seed, (uint64_t)bg * 1000003ull + step, v);
+        if (temperature > 0.f) {
+            const float uu = rng_uniform(seed, (uint64_t)bg * 1000003ull + step, v);
             mixed = mixed * invT - __logf(-__logf(uu));
         }
         if (mixed > best) { best = mixed; bi = v; }
@@ -535,12 +550,13 @@ __global__ __launch_bounds__(256) void cfg_pick_kernel(SampleArgs a, const float
         i = i < 0 ? 0 : (i >= a.V ? a.V - 1 : i);
         int emit = i, feed = i;
         const long bg = b + a.b_off;
-        if (step < a.T && a.force_tok) {
-            const int f = a.force_tok[bg * a.T + step];
-            if (a.force_mask) { if (a.force_mask[bg * a.T + step] == 0) { emit = f; feed = f; } }
+        const int T = a.p->T;
+        if (step < T && a.p->has_force) {
+            const int f = a.force_tok[bg * T + step];
+            if (a.p->has_mask) { if (a.force_mask[bg * T + step] == 0) { emit = f; feed = f; } }
             else feed = f;
         }
-        if (step < a.T) a.out_tok[bg * a.T + step] = emit;
+        if (step < T) a.out_tok[bg * T + step] = emit;
         feed = feed < 0 ? 0 : (feed >= a.V ? a.V - 1 : feed);
         s_tok = feed;
     }
@@ -553,6 +569,10 @@ __global__ __launch_bounds__(256) void cfg_pick_kernel(SampleArgs a, const float
         *(f32x4*)(x0 + a.H + i) = v;
     }
 }
+__global__ void set_sample_params_kernel(SampleParams* dst, SampleParams v) { *dst = v; }
+void launch_set_sample_params(hipStream_t s, SampleParams* dst, SampleParams v) { hipLaunchKernelGGL(set_sample_params_kernel, dim3(1), dim3(1), 0, s, dst, v); }
+__global__ void set_text_params_kernel(TextParams* dst, TextParams v) { *dst = v; }
+void launch_set_text_params(hipStream_t s, TextParams* dst, TextParams v) { hipLaunchKernelGGL(set_text_params_kernel, dim3(1), dim3(1), 0, s, dst, v); }
 void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B, float* scratch_v, int* scratch_i) {
     hipLaunchKernelGGL(cfg_scan_kernel, dim3(CFG_CHUNKS, B), dim3(256), 0, s, a, scratch_v, scratch_i);
     hipLaunchKernelGGL(cfg_pick_kernel, dim3(B), dim3(256), 0, s, a, scratch_v, scratch_i);
@@ -563,13 +583,14 @@ void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B, float* scratch
 __global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a) {
     __shared__ float sv[4]; __shared__ int si[4]; __shared__ int s_tok;
     const int b = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
+    const int eos = a.p->eos, min_new = a.p->min_new, max_new = a.p->max_new;
     float best = -INFINITY; int bi = 0x7fffffff;
     for (int v = tid; v < a.V; v += 256) {
         float c1[1] = {0.f};
         const int oc1[1] = {0};
         sum_slabs<1>(a.logits_partial + (long)b * a.V + v, a.slab, a.S, oc1, c1);
         float c = c1[0];
-        if (v == a.eos && step < a.min_new) c = -INFINITY;
+        if (v == eos && step < min_new) c = -INFINITY;
         if (c > best) { best = c; bi = v; }
     }
 #pragma unroll
@@ -583,9 +604,9 @@ __global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a) {
         float v = sv[0]; int i = si[0];
         for (int k = 1; k < 4; ++k) argmax_combine(v, i, sv[k], si[k]);
         const int unf = a.unfinished[b];
-        const int tok = unf ? i : a.eos;
-        if (step < a.max_new) a.out[(long)b * a.max_new + step] = tok;
-        const int still = unf && (tok != a.eos);
+        const int tok = unf ? i : eos;
+        if (step < max_new) a.out[(long)b * max_new + step] = tok;
+        const int still = unf && (tok != eos);
         a.unfinished[b] = still;
         if (still) atomicOr(a.any_unfinished + ((step + 1) & 1023), 1);
         s_tok = tok < 0 ? 0 : (tok >= a.V ? a.V - 1 : tok);
@@ -597,6 +618,19 @@ __global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a) {
 }
 void launch_text_argmax(hipStream_t s, const TextArgs& a, int B) {
     hipLaunchKernelGGL(text_argmax_kernel, dim3(B), dim3(256), 0, s, a);
+}
+
+// test tap: the sampler's uniform / Gumbel transform of raw 64-bit RNG outputs: out[i] = u, out[n+i] = -log(-log(u))
+__global__ void uniform_from_bits_kernel(const uint64_t* __restrict__ z, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float u = uniform_from_bits(z[i]);
+    out[i] = u;
+    out[n + i] = -__logf(-__logf(u));
+}
+void launch_uniform_from_bits(hipStream_t s, const uint64_t* z, float* out, int n) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(uniform_from_bits_kernel, dim3((n + 255) / 256), dim3(256), 0, s, z, out, n);
 }
 
 __global__ void advance_kernel(int32_t* n) { *n += 1; }

@@ -122,9 +122,10 @@ class Engine:
         return {k: getattr(t, k) for k, _ in t._fields_}
 
     # ------------------------------------------------------------------ weights
-    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> Tuple[int, list]:
-        """Load tensors by their reference state_dict names (HF Janus-Pro-1B keys, optionally
-        with PlanGen's ``vl_gpt.`` prefix).  Returns (#loaded, skipped names)."""
+    def load_tensors(self, sd: Dict[str, torch.Tensor]) -> Tuple[int, list]:
+        """Hand tensors to ``pg_load_tensor`` by their reference state_dict names (HF Janus-Pro-1B keys,
+        optionally with PlanGen's ``vl_gpt.`` prefix) WITHOUT finalizing: callers streaming a checkpoint in
+        groups call this per group and :meth:`finalize` once.  Returns (#loaded, names the engine does not own)."""
         loaded, skipped = 0, []
         for name, t in sd.items():
             t = t.detach()
@@ -138,10 +139,24 @@ class Engine:
                 continue
             self._check(rc, f"pg_load_tensor({name})")
             loaded += 1
+        return loaded, skipped
+
+    def finalize(self, strict: bool = True) -> int:
+        """``pg_finalize_weights``: derived tables + decode weight layouts, once per checkpoint.  strict: raise when a
+        required tensor was never loaded; otherwise the engine is told to run with the missing ones reading as zeros
+        (``load_state_dict(strict=False)`` semantics of base_system.py:153-155).  Returns the number missing."""
+        if not strict:
+            self.set_option("allow_partial_weights", 1)
         missing = C.c_int(0)
         self._check(self.lib.pg_finalize_weights(self.h, C.byref(missing), self.stream), "pg_finalize_weights")
         if strict and missing.value:
             raise PlanGenError(f"{missing.value} required tensors missing; first: {self.lib.pg_last_error(self.h).decode()}")
+        return missing.value
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> Tuple[int, list]:
+        """load_tensors + finalize.  Returns (#loaded, skipped names)."""
+        loaded, skipped = self.load_tensors(sd)
+        self.finalize(strict)
         return loaded, skipped
 
     def init_synthetic(self, seed: int = 0, std: float = 0.02):
@@ -409,6 +424,39 @@ class Engine:
         self._check(self.lib.pg_op_gemm(self.h, self._p(a), self._p(w), self._p(out), M, N, K, kind, C.byref(S), self.stream), "pg_op_gemm")
         torch.cuda.synchronize()
         return out[:S.value].sum(0)
+
+    def op_gemm_splits(self, a: torch.Tensor, w: torch.Tensor) -> int:
+        """Split-K slab count the decode GEMM picks for this shape under THIS handle's tuning."""
+        a = self._dev(a, self.tdtype); w = self._dev(w, self.tdtype)
+        M, K = a.shape
+        N = w.shape[0]
+        out = torch.zeros((64, M, N), dtype=torch.float32, device=self.device)
+        S = C.c_int(0)
+        self._check(self.lib.pg_op_gemm(self.h, self._p(a), self._p(w), self._p(out), M, N, K, 1, C.byref(S), self.stream), "pg_op_gemm")
+        torch.cuda.synchronize()
+        return S.value
+
+    def op_swiglu_gemm(self, a: torch.Tensor, w_gate: torch.Tensor, w_up: torch.Tensor) -> torch.Tensor:
+        """down-proj input of LlamaMLP: silu(a @ w_gate^T) * (a @ w_up^T) through the decode kernel (tiled weights,
+        SwiGLU epilogue).  The gate/up rows are interleaved in blocks of 8 here, like pg_load_tensor does."""
+        a = self._dev(a, torch.bfloat16)
+        I, K = w_gate.shape
+        wgu = torch.stack([w_gate.reshape(I // 8, 8, K), w_up.reshape(I // 8, 8, K)], dim=1).reshape(2 * I, K)
+        wgu = self._dev(wgu, torch.bfloat16)
+        M = a.shape[0]
+        out = torch.empty((M, I), dtype=torch.bfloat16, device=self.device)
+        self._check(self.lib.pg_op_swiglu_gemm(self.h, self._p(a), self._p(wgu), self._p(out), M, I, K, self.stream), "pg_op_swiglu_gemm")
+        torch.cuda.synchronize()
+        return out
+
+    def op_uniform(self, bits: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(u, gumbel) the sampler derives from raw 64-bit RNG outputs (int64 tensor = the bit patterns)."""
+        b = self._dev(bits.reshape(-1), torch.int64)
+        n = b.numel()
+        out = torch.empty((2 * n,), dtype=torch.float32, device=self.device)
+        self._check(self.lib.pg_op_uniform(self.h, self._p(b), self._p(out), n, self.stream), "pg_op_uniform")
+        torch.cuda.synchronize()
+        return out[:n], out[n:]
 
     def op_conv3x3(self, x_nhwc: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor, residual=None, up: int = 0,
                    stride2: int = 0) -> torch.Tensor:

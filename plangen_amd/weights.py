@@ -47,19 +47,28 @@ def latest_checkpoint(out_dir: str) -> Optional[str]:
 
 
 def load_checkpoint(engine: Engine, janus_path: str, overlay: Optional[str] = None, strict: bool = True) -> Dict[str, List[str]]:
-    """Load base weights then the PlanGen overlay (later tensors replace earlier ones)."""
+    """Load base weights then the PlanGen overlay (later tensors replace earlier ones); the engine's derived
+    tables and decode layouts are built ONCE at the end (``Engine.finalize``)."""
     skipped: List[str] = []
     loaded = 0
     sd = {}
     for name, t in iter_safetensors(janus_path):
         sd[name] = t
-        if len(sd) >= 64:                         # bounded host memory: flush in groups
-            n, sk = engine.load_state_dict(sd, strict=False)
+        if len(sd) >= 64:                         # bounded host memory: hand over in groups, finalize once
+            n, sk = engine.load_tensors(sd)
             loaded += n; skipped += sk; sd = {}
+    n, sk = engine.load_tensors(sd)
+    loaded += n; skipped += sk
     if overlay:
         path = overlay if overlay.endswith(".pth") else os.path.join(overlay, "trainable_model_parameters.pth")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"PlanGen overlay not found: {path}")
         ov = torch.load(path, map_location="cpu", weights_only=True)
-        sd.update(ov)                             # "vl_gpt." prefix is stripped by pg_load_tensor
-    n, sk = engine.load_state_dict(sd, strict=strict)
-    loaded += n; skipped += sk
+        n, sk = engine.load_tensors(ov)           # "vl_gpt." prefix is stripped by pg_load_tensor
+        if ov and n == 0:
+            # e.g. a LoRA-only checkpoint (lora_A / lora_B keys): nothing of it would take effect
+            raise PlanGenError(f"overlay {path}: none of its {len(ov)} tensors is a weight of this engine "
+                               f"(first key {next(iter(ov))!r}); refusing to run the base weights silently")
+        loaded += n; skipped += sk
+    engine.finalize(strict)
     return {"loaded": [str(loaded)], "skipped": skipped}

@@ -138,3 +138,101 @@ def test_cli_validation_writes_images(tmp_path):
     assert res["images"] == 4
     files = os.listdir(res["out_dir"])
     assert sum(f.endswith((".png", ".pt")) for f in files) == 4 and sum(f.endswith("_tokens.json") for f in files) == 2
+
+
+def test_decode_graph_survives_fresh_buffers_seeds_and_temperatures(tiny_cfg, tiny_weights, ocfg):
+    """the decode-step graph is keyed on shapes only; seeds, temperatures, T and the caller's
+    output / forcing tensors reach it through library-owned device memory.  Calls with fresh tensors must keep
+    producing the right tokens (greedy == oracle), seeded sampling must be reproducible, and seeds must matter."""
+    e = get_engine(tiny_cfg, tiny_weights, "f32")
+    g = torch.Generator().manual_seed(71)
+    cond = [torch.randint(8, tiny_cfg.vocab, (n,), generator=g).tolist() for n in (7, 11)]
+    neg = torch.randint(8, tiny_cfg.vocab, (5,), generator=g).tolist()
+    ids, mask = _collate(tiny_cfg, cond, neg)
+    pad = _pad(mask, ids.shape[1])
+    ref = R.sample_image(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, 5.0, n_tokens=10)
+    outs = []
+    for seed, temp in ((0, 0.0), (3, 1.0), (4, 1.0), (3, 1.0), (9, 0.0)):
+        e.prefill(ids, pad)
+        outs.append(e.decode_image_tokens(T=10, cfg_weight=5.0, temperature=temp, seed=seed).cpu())
+    assert torch.equal(outs[0], ref) and torch.equal(outs[4], ref)
+    assert torch.equal(outs[1], outs[3]) and not torch.equal(outs[1], outs[2])
+    # forcing tensors change between calls (teacher forcing) on the same graph
+    force = torch.randint(0, tiny_cfg.img_vocab, (2, 10), generator=g).int()
+    ref_f = R.sample_image(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, 5.0, n_tokens=10, force_tokens=force)
+    e.prefill(ids, pad)
+    assert torch.equal(e.decode_image_tokens(T=10, cfg_weight=5.0, temperature=0.0, force_tokens=force).cpu(), ref_f)
+    e.prefill(ids, pad)
+    assert torch.equal(e.decode_image_tokens(T=7, cfg_weight=5.0, temperature=0.0).cpu(), ref[:, :7])
+
+
+def test_sampled_frequencies_follow_softmax_chi_square(tiny_cfg, tiny_weights, ocfg):
+    """chi-square test of sampled token frequencies against softmax(mixed logits / T) on the small
+    vocabulary (V=256).  Teacher forcing fixes the context, so the distribution of step t of image b is known
+    from the oracle; 600 seeds x 3 steps x 2 images, categories with expected count < 5 pooled."""
+    from scipy import stats
+    e = get_engine(tiny_cfg, tiny_weights, "f32")
+    g = torch.Generator().manual_seed(72)
+    cond = [torch.randint(8, tiny_cfg.vocab, (n,), generator=g).tolist() for n in (9, 6)]
+    neg = torch.randint(8, tiny_cfg.vocab, (4,), generator=g).tolist()
+    ids, mask = _collate(tiny_cfg, cond, neg)
+    pad = _pad(mask, ids.shape[1])
+    T, N, temp = 3, 600, 1.3
+    force = torch.randint(0, tiny_cfg.img_vocab, (2, T), generator=g).int()
+    _, logits = R.sample_image(tiny_weights, ocfg, R.embed_tokens(tiny_weights, ids), mask, 2.0, n_tokens=T,
+                               force_tokens=force, return_logits=True)           # [T, B, V]
+    draws = []
+    for seed in range(N):
+        e.prefill(ids, pad)
+        draws.append(e.decode_image_tokens(T=T, cfg_weight=2.0, temperature=temp, seed=seed, force_tokens=force).cpu())
+    draws = torch.stack(draws)                                                   # [N, B, T]
+    p = torch.softmax(logits.double() / temp, dim=-1)                            # [T, B, V]
+    for t in range(T):
+        for b in range(2):
+            exp = p[t, b] * N
+            obs = torch.bincount(draws[:, b, t].long(), minlength=tiny_cfg.img_vocab).double()
+            big = exp >= 5
+            o = torch.cat([obs[big], obs[~big].sum()[None]])
+            x = torch.cat([exp[big], exp[~big].sum()[None]])
+            chi2 = ((o - x) ** 2 / x).sum().item()
+            pval = 1 - stats.chi2.cdf(chi2, df=len(o) - 1)
+            assert pval > 1e-4, (t, b, chi2, pval)
+
+
+def test_transposed_or_missing_weights_are_refused(tiny_cfg, tiny_weights):
+    """a tensor with the right element count and the wrong shape is rejected; an engine with
+    required tensors missing refuses to run unless the caller opted in with strict=False."""
+    from plangen_amd.engine import Engine, PlanGenError
+    e = Engine(tiny_cfg, dtype="f32", max_rows=2, max_prompt=8, max_images=1)
+    name = "language_model.model.layers.0.mlp.down_proj.weight"
+    with pytest.raises(PlanGenError, match="shape"):
+        e.load_tensors({name: tiny_weights[name].t().contiguous()})
+    part = {k: v for k, v in tiny_weights.items() if "layers.1." not in k}
+    e.load_tensors(part)
+    with pytest.raises(PlanGenError, match="missing"):
+        e.finalize(strict=True)
+    with pytest.raises(PlanGenError):
+        e.prefill(torch.tensor([[9, 10], [9, 11]], dtype=torch.int32), [0, 0])
+    assert e.finalize(strict=False) > 0                      # opt-in: missing tensors read as zeros
+    e.prefill(torch.tensor([[9, 10], [9, 11]], dtype=torch.int32), [0, 0])
+    toks = e.decode_image_tokens(T=2, cfg_weight=5.0, temperature=0.0)
+    assert toks.shape == (1, 2)
+    e.close()
+
+
+def test_two_handles_keep_their_own_tuning(tiny_cfg, tiny_weights):
+    """pg_set_option is per handle."""
+    from plangen_amd.engine import Engine
+    a = get_engine(tiny_cfg, tiny_weights, "bf16")
+    b = Engine(tiny_cfg, dtype="bf16", max_rows=4, max_prompt=16, max_images=1)
+    b.load_state_dict({k: v for k, v in tiny_weights.items()
+                       if not k.startswith(("vision_model.", "aligner.", "gen_vision_model.encoder", "gen_vision_model.quant_conv", "language_model.lm_head"))})
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(100, 2048, generator=g).bfloat16()
+    w = (torch.randn(1024, 2048, generator=g) * 0.05).bfloat16()
+    b.set_option("split_target_big", 4096)                  # b wants many split-K slabs at M >= 96, a keeps its default
+    S_a = a.op_gemm_splits(x, w)
+    S_b = b.op_gemm_splits(x, w)
+    assert S_b > S_a
+    assert a.op_gemm_splits(x, w) == S_a
+    b.close()

@@ -164,3 +164,72 @@ def test_conv3x3_halo_tile_path(tiny_cfg, tiny_weights, res, B, Hs, Ws, up):
     assert torch.equal(out, out_gemm)
     o = out.float().cpu().permute(0, 3, 1, 2)
     assert (o - ref).abs().max() < 2e-2 * ref.abs().max()
+
+
+def test_sampler_uniform_strictly_inside_unit_interval(tiny_cfg, tiny_weights):
+    """with 24 random bits (x + 0.5) / 2^24 rounds to exactly 1.0 for the top counter value
+    and the Gumbel term becomes +inf.  Sweep the top / bottom counter values of the generator output through
+    the sampler's own transform: u must stay in (0, 1) and the Gumbel noise finite."""
+    e = _eng(tiny_cfg, tiny_weights, "f32")
+    top = [(1 << 64) - 1 - i for i in range(4096)] + [((1 << 23) - 1 - i) << 41 for i in range(64)]
+    bot = list(range(4096)) + [i << 41 for i in range(64)]
+    g = torch.Generator().manual_seed(0)
+    rnd = torch.randint(-(1 << 62), 1 << 62, (1 << 16,), generator=g, dtype=torch.int64).tolist()
+    bits = torch.tensor([b - (1 << 64) if b >= (1 << 63) else b for b in top + bot] + rnd, dtype=torch.int64)
+    u, gum = e.op_uniform(bits)
+    u, gum = u.cpu(), gum.cpu()
+    assert (u > 0).all() and (u < 1).all()
+    assert torch.isfinite(gum).all()
+    assert u.max().item() == 1.0 - 2.0 ** -24 and u.min().item() == 2.0 ** -24
+    # the transform is the stated one: 23 high bits, centred
+    want = ((bits.numpy().astype("uint64") >> 41).astype("float64") + 0.5) / 2 ** 23
+    assert (u.double().numpy() == want).all()
+    assert abs(u[-(1 << 16):].mean().item() - 0.5) < 0.01
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 6144, 2048), (128, 2048, 2048), (128, 2048, 5632), (128, 16384, 2048),
+                                   (64, 6144, 2048), (16, 2048, 5632), (8, 2048, 2048), (100, 512, 1408)])
+def test_skinny_gemm_on_tiled_decode_weights(tiny_cfg, tiny_weights, M, N, K):
+    """The decode layout: W re-tiled [n-tile 16][k-chunk 128][k-step][lane][8] exactly like
+    pg_finalize_weights does, streamed by gemm_skinny3_kernel<.., TILED> at the Janus-Pro shapes the bs=64 bench
+    runs (qkv NCK 8, o NCK 4, down NCK 11, gen_head) -- against fp64 and bit-for-bit against the row-major path."""
+    e = _eng(tiny_cfg, tiny_weights, "bf16")
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _round(torch.randn(M, K, generator=g), "bf16")
+    w = _round(torch.randn(N, K, generator=g) * torch.linspace(0.5, 2.0, N)[:, None] * 0.05, "bf16")
+    out_t = e.op_gemm(a, w, 4).cpu()
+    out_r = e.op_gemm(a, w, 1).cpu()
+    ref = a.double() @ w.double().t()
+    err = (out_t.double() - ref).abs().max().item()
+    assert err < 2e-4 * ref.abs().max().item() + 1e-4, err
+    assert (out_t - out_r).abs().max().item() < 1e-4 * ref.abs().max().item() + 1e-5     # same products, M-block geometry may differ
+
+
+@pytest.mark.parametrize("M,I,K", [(128, 5632, 2048), (64, 5632, 2048), (16, 5632, 2048), (8, 512, 256)])
+def test_decode_swiglu_gemm_epilogue(tiny_cfg, tiny_weights, M, I, K):
+    """gate|up GEMM with SwiGLU fused into the epilogue (gemm_skinny3_kernel<.., NCK 16, EPI 1, TILED>) at the
+    bench shape vs torch: h = silu(x Wg^T) * (x Wu^T), bf16 out."""
+    e = _eng(tiny_cfg, tiny_weights, "bf16")
+    g = torch.Generator().manual_seed(M + I)
+    a = _round(torch.randn(M, K, generator=g), "bf16")
+    wg = _round(torch.randn(I, K, generator=g) * 0.03, "bf16")
+    wu = _round(torch.randn(I, K, generator=g) * torch.linspace(0.5, 2.0, I)[:, None] * 0.03, "bf16")
+    out = e.op_swiglu_gemm(a, wg, wu).float().cpu()
+    ref = (F.silu(a.double() @ wg.double().t()) * (a.double() @ wu.double().t())).float()
+    assert (out - ref).abs().max() < 1e-2 * ref.abs().max()          # one bf16 rounding of h
+
+
+@pytest.mark.parametrize("H,NV", [(2048, 2), (4096, 4)])
+def test_rmsnorm_wide_rows(tiny_cfg, tiny_weights, H, NV):
+    """rmsnorm_kernel<bf16, 2> (H = 2048: the bench's instantiation) and <bf16, 4>, with 4 split-K slabs."""
+    e = _eng(tiny_cfg, tiny_weights, "bf16")
+    g = torch.Generator().manual_seed(H)
+    M = 128
+    x = torch.randn(M, H, generator=g)
+    part = torch.randn(4, M, H, generator=g)
+    w = _round(1 + 0.1 * torch.randn(H, generator=g), "bf16")
+    xnew, out = e.op_rmsnorm(x, w, 1e-6, part)
+    xr = x + part.sum(0)
+    ref = w * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert torch.allclose(xnew.cpu(), xr, atol=1e-5)
+    assert (out.float().cpu() - ref).abs().max() < 1e-2 * ref.abs().max()
