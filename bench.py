@@ -4,21 +4,34 @@
 One "step" = one full pass of the path over one batch of synthetic prompts per GPU:
 prefill of 2B CFG rows (left-padded to L) -> 576-step CFG decode loop (multinomial sampling at
 temperature 1 via Gumbel-max, same cost as greedy) -> VQ-16 decode to B 384x384 images.
-Inputs (token ids) are resident in HBM before the timed region.  Multi-GPU: prompts are
-sharded over ranks (weak scaling: B images per GPU), rank 0 broadcasts the collated ids over
-RCCL, no collective inside the loop, tokens all-gathered at the end.
+Inputs (token ids) are resident in HBM before the timed region.
+
+Multi-GPU: prompts are sharded over ranks, one process per GPU; rank 0 broadcasts the
+collated ids over RCCL, no collective inside the loop, tokens gathered to rank 0 at the end.
+  python bench.py --gpus N                      spawns N ranks itself (fresh child processes; the parent
+                                                never touches a GPU) and relays rank 0's JSON line
+  python -m torch.distributed.run ... bench.py --gpus N    runs as the rank the launcher made it
+  default: weak scaling, --batch images per GPU;  --global-batch G (BASELINE configs[3]: 256 over 8 GPUs):
+  strong scaling, G / N images per GPU.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable float4 copy)
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
+WEIGHT_PARAMS_LAYER = 51_380_224          # SURVEY App. A [probe]
+VQ_DECODE_GFLOP_PER_IMAGE = 567.40 + 4 * 0.68   # SURVEY 8d / App. C conv + AttnBlock FLOPs
 
 
 def synth_prompts(B, L, vocab, pad_id, seed):
@@ -81,12 +94,14 @@ def cpu_baseline(L, steps_sample, threads):
             "image_tokens_per_s": 576.0 / (t_prefill + 576 * t_step)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE: bs=64)")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU (BASELINE: bs=64); weak scaling")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total images over all GPUs (BASELINE configs[3]: 256 over 8 GPUs); strong scaling")
     ap.add_argument("--prompt-len", type=int, default=256)
     ap.add_argument("--tokens", type=int, default=None, help="image tokens per image (default 576)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -94,10 +109,82 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="tiny config (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-shard-check", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=64)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--time-stride", type=int, default=8, help="instrumented pass: time every n-th decode step")
     ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=value (pg_set_option)")
-    args = ap.parse_args()
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher dry run (no GPU): every rank checks its env, joins a gloo group, all-reduces, rank 0 prints JSON")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """Start ``n`` fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), wait, relay
+    rank 0's stdout.  The parent has not touched the GPU (no torch.cuda call, no HIP call) and never execs."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PG_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: ranks failed (rank, rc): {bad}\n")
+        return 1
+    return 0
+
+
+def launch_check(args, world, rank):
+    """No-GPU dry run of the multi-rank plumbing (CPU test of the launcher)."""
+    import torch
+    import torch.distributed as dist
+    from plangen_amd.dist import gather_rows, shard_range
+    assert world == args.gpus, (world, args.gpus)
+    assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    G = args.global_batch or args.batch * world
+    lo, hi = shard_range(G, world, rank)
+    rows = gather_rows(torch.arange(lo, hi, dtype=torch.int32)[:, None].repeat(1, 3), G)
+    if rank == 0:
+        ok = float(t) == world * (world + 1) / 2 and rows[:, 0].tolist() == list(range(G))
+        print(json.dumps({"launch_check": "ok" if ok else "FAILED", "world": world, "global_images": G,
+                          "images_rank0": hi - lo, "backend": "gloo"}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled number\n")
+        return 2
+    if args.launch_check:
+        return launch_check(args, world, rank)
 
     import torch
     import torch.distributed as dist
@@ -105,13 +192,11 @@ def main():
     from plangen_amd.dist import broadcast_prompts, gather_rows
     from plangen_amd.engine import Engine
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("PG_FORCE_DEVICE") is not None:      # debugging aid: several ranks on one GPU (gloo only)
         local = int(os.environ["PG_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PG_DIST_BACKEND", "nccl")    # "nccl" is RCCL on ROCm
@@ -121,7 +206,13 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = PlanGenConfig.tiny() if args.tiny else PlanGenConfig.janus_pro_1b()
-    B, L = args.batch, args.prompt_len
+    L = args.prompt_len
+    strong = args.global_batch is not None
+    G = args.global_batch if strong else args.batch * world              # images in the global batch
+    if G % world:
+        sys.stderr.write(f"bench.py: global batch {G} does not divide over {world} ranks\n")
+        return 2
+    B = G // world
     T = args.tokens or cfg.img_tokens
     eng = Engine(cfg, dtype=args.dtype, max_rows=2 * B, max_prompt=L, max_new=cfg.img_tokens, max_images=B, device=local)
     eng.init_synthetic(seed=0)
@@ -129,20 +220,21 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
 
-    # rank 0 collates the global batch (B images per rank) and broadcasts it over RCCL
+    # rank 0 collates the global batch and broadcasts it over RCCL; every rank keeps its contiguous slice
     if rank == 0:
-        g_ids, g_mask = synth_prompts(B * world, L, cfg.vocab, cfg.pad_id, seed=0)
-        g_mask = torch.cat([g_mask, torch.ones((2 * B * world, cfg.img_tokens), dtype=torch.int32)], dim=1)
+        g_ids, g_mask = synth_prompts(G, L, cfg.vocab, cfg.pad_id, seed=0)
+        g_mask = torch.cat([g_mask, torch.ones((2 * G, cfg.img_tokens), dtype=torch.int32)], dim=1)
     else:
         g_ids = g_mask = None
     ids, mask, lo, hi, nB = broadcast_prompts(g_ids, g_mask, dev)
     pad = Engine.pad_len_from_mask(mask, L)
+    eng.set_option("rng_image_offset", lo)       # sampling noise keyed on the GLOBAL image index: sharding does not change tokens
 
-    def step(seed):
+    def step(seed, n_tok=T, decode_pixels=True):
         eng.prefill(ids, pad, position_mode=0)
-        toks = eng.decode_image_tokens(T=T, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=seed)
-        img = eng.vq_decode(toks) if T == cfg.img_tokens else None
-        all_toks = gather_rows(toks, nB)
+        toks = eng.decode_image_tokens(T=n_tok, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=seed)
+        img = eng.vq_decode(toks) if (decode_pixels and n_tok == cfg.img_tokens) else None
+        all_toks = gather_rows(toks, nB)          # rank 0: [G, T]; others: None
         return all_toks, img
 
     def fence():
@@ -158,51 +250,113 @@ def main():
     for k in range(args.steps):
         step(k)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    rank_ms = [dt_local / max(args.steps, 1) * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        rank_ms = [float(v.item()) / max(args.steps, 1) * 1e3 for v in ts]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = eng.timing()
-    images = B * world * args.steps
+    images = G * args.steps
     out = {
         "metric": "images/sec, 384px layout2image (576 image tokens, CFG, VQ-16 decode), bs=%d per MI355X" % B,
         "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic prompts (SURVEY 8d), seeded random-init Janus-Pro-1B-shaped weights",
-        "config": {"workload": "task_type='uni' layout2image, %dx%d / %d image tokens, bs=%d per GPU, L=%d left-padded, "
-                               "cfg_weight=%g, temperature=%g" % (cfg.img_size, cfg.img_size, T, B, L, cfg.cfg_weight, args.temperature),
-                   "images_per_gpu": B, "prompt_len": L, "rows_per_gpu": 2 * B, "parallelism": "prompt-sharded x%d" % world},
+        "config": {"workload": "task_type='uni' layout2image, %dx%d / %d image tokens, bs=%d per GPU (global %d), L=%d left-padded, "
+                               "cfg_weight=%g, temperature=%g" % (cfg.img_size, cfg.img_size, T, B, G, L, cfg.cfg_weight, args.temperature),
+                   "images_per_gpu": B, "global_batch": G, "prompt_len": L, "rows_per_gpu": 2 * B,
+                   "parallelism": "prompt-sharded x%d" % world},
         "image_tokens_per_sec_per_gpu": B * T * args.steps / dt,
         "last_step_ms": {"prefill": tm["prefill_ms"], "decode_loop": tm["decode_ms"], "vq_decode": tm["vq_ms"]},
         "device_gb": eng.device_bytes() / 2 ** 30,
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": backend,
+        "rank_ms_per_step": rank_ms,
     }
 
-    if not args.no_roofline:
-        # Dominant kernel = decode attention (HBM-bound KV streaming).  Instrumented pass right
-        # after the timed region: same batch, eager launches, hipEvents on the launch stream
-        # around every decode-attention launch (24 layers x 575 steps).
+    if world > 1 and not args.no_shard_check:
+        # The gathered token matrix must equal what ONE rank produces for the same seed: all ranks run a short
+        # sampled pass (32 tokens), rank 0 then regenerates every other rank's shard itself (same prompts, same
+        # global image indices in the RNG) and compares bit for bit.
+        from plangen_amd.dist import shard_range
+        n_chk = min(32, T)
+        gathered, _ = step(4242, n_tok=n_chk, decode_pixels=False)
+        if rank == 0:
+            bad = 0
+            for r in range(1, world):
+                rlo, rhi = shard_range(G, world, r)
+                ids_r = g_ids[2 * rlo:2 * rhi].to(dev)
+                pad_r = Engine.pad_len_from_mask(g_mask[2 * rlo:2 * rhi], L)
+                eng.set_option("rng_image_offset", rlo)
+                eng.prefill(ids_r, pad_r, position_mode=0)
+                mine = eng.decode_image_tokens(T=n_chk, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=4242)
+                bad += int((mine.cpu() != gathered[rlo:rhi].cpu()).sum())
+            eng.set_option("rng_image_offset", lo)
+            out["shard_check"] = {"tokens_compared": int((G - (hi - lo)) * n_chk), "mismatches": bad,
+                                  "what": "gathered tokens of ranks 1..N-1 == rank 0's own run of those shards, same seed"}
+        fence()
+
+    if not args.no_roofline and rank == 0:
+        # Instrumented pass right after the timed region: same batch, eager launches, hipEvents on the launch
+        # stream around every decode kernel class on every --time-stride-th step (the timed region replays a hipGraph,
+        # which cannot carry events between nodes).  Dominant kernel = decode attention (HBM-bound K/V streaming).
         eng.set_option("time_attn", 1)
+        eng.set_option("time_stride", args.time_stride)
         eng.prefill(ids, pad, position_mode=0)
         eng.decode_image_tokens(T=T, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=99)
         torch.cuda.synchronize()
         ta = eng.timing()
+        cls = eng.class_timing()
         eng.set_option("time_attn", 0)
         if ta["attn_launches"]:
             ach = ta["attn_bytes_sum"] / (ta["attn_ms_sum"] * 1e-3) / 1e9
-            # PMC traffic cannot be collected from inside this process: it comes from separate
-            # rocprofv3 --pmc passes of this same command (profiles/r01_b_pmc_attn_traffic.md);
-            # the measured traffic / algorithmic ratio of the kernel is applied to this run's bytes.
+            kname = "attn_decode_fused_kernel"
+            # PMC traffic cannot be collected from inside this process: it comes from separate rocprofv3 --pmc
+            # passes of this same command (tools/pmc_traffic.py writes profiles/pmc_attn.json with the kernel symbol
+            # and the commit it was measured at).  A ratio measured on another kernel symbol is not applied.
             traffic = None
             pj = os.path.join(ROOT, "profiles", "pmc_attn.json")
             if os.path.exists(pj):
-                ratio = json.load(open(pj))["traffic_per_algorithmic_byte"]
-                traffic = ratio * ta["attn_bytes_sum"] / ta["attn_launches"]
-            out["roofline"] = {"bound": "hbm", "kernel": "attn_decode_fused_kernel (RoPE + KV append + decode attention)",
-                               "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+                pm = json.load(open(pj))
+                if pm.get("kernel_symbol", "").startswith(kname) and pm.get("kernel_src_sha") == kernel_src_sha():
+                    traffic = pm["traffic_per_algorithmic_byte"] * ta["attn_bytes_sum"] / ta["attn_launches"]
+            out["roofline"] = {"bound": "hbm", "kernel": kname + " (RoPE + KV append + decode attention)",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "launches": ta["attn_launches"], "avg_launch_us": ta["attn_ms_sum"] / ta["attn_launches"] * 1e3,
                                "algorithmic_bytes_per_launch": ta["attn_bytes_sum"] / ta["attn_launches"],
-                               "decode_loop_share": ta["attn_ms_sum"] / max(ta["decode_ms"], 1e-9)}
+                               "decode_loop_share": ta["attn_ms_sum"] * args.time_stride / max(ta["decode_ms"], 1e-9),
+                               "timed_every_nth_step": args.time_stride}
+            classes = {}
+            for name, c in cls.items():
+                if not c["launches"]:
+                    continue
+                gbs = c["bytes_sum"] / (c["ms_sum"] * 1e-3) / 1e9
+                classes[name] = {"bound": "hbm", "avg_launch_us": c["ms_sum"] / c["launches"] * 1e3,
+                                 "algorithmic_mb_per_launch": c["bytes_sum"] / c["launches"] / 1e6,
+                                 "achieved_gbs": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": c["launches"]}
+            if not args.tiny and T == cfg.img_tokens:
+                # MFMA-bound phases, whole-phase times of the LAST TIMED step (HIP events inside the library):
+                ntok = sum(L - p for i, p in enumerate(pad) if i % 2 == 0) + (L - pad[1])        # shared uncond prompt prefilled once
+                lens = [L - p for i, p in enumerate(pad) if i % 2 == 0] + [L - pad[1]]
+                fl = 2.0 * ntok * cfg.n_layers * WEIGHT_PARAMS_LAYER + sum(4.0 * cfg.n_layers * cfg.hidden * n * (n + 1) / 2 for n in lens)
+                tf = fl / (tm["prefill_ms"] * 1e-3) / 1e12
+                classes["prefill (packed GEMMs + flash attention)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["prefill_ms"],
+                                                                       "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
+                fl = VQ_DECODE_GFLOP_PER_IMAGE * 1e9 * B
+                tf = fl / (tm["vq_ms"] * 1e-3) / 1e12
+                classes["vq_decode (convs + GroupNorm + AttnBlock)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["vq_ms"],
+                                                                        "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
+            out["roofline"]["classes"] = classes
+            dsum = sum(c["ms_sum"] for n, c in cls.items() if n.startswith("decode_gemm") or n == "decode_rmsnorm")
+            dby = sum(c["bytes_sum"] for n, c in cls.items() if n.startswith("decode_gemm"))
+            if dsum > 0:
+                out["roofline"]["decode_gemm_norm_phase"] = {"weight_gbs": dby / (dsum * 1e-3) / 1e9,
+                                                             "frac": dby / (dsum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                             "ms_per_step": dsum / max(1, cls["decode_gemm_qkv"]["launches"] // cfg.n_layers)}
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
@@ -211,9 +365,26 @@ def main():
         out["cpu_baseline"] = cpu_baseline(L, args.cpu_steps, min(args.cpu_threads, os.cpu_count() or 1))
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def kernel_src_sha():
+    """Identity of the decode-attention kernel source a PMC ratio belongs to (stale ratios are dropped)."""
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "plangen_amd", "csrc", "llm_kernels.hip"), "rb").read()).hexdigest()[:16]
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # parent: start N fresh rank processes; no torch.cuda / HIP call has happened in this process
+        return spawn_ranks(args.gpus, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -15,7 +15,8 @@
  *     "host" pointers are small per-row metadata in host memory.
  *   - the library owns weights, KV cache and workspaces (hipMalloc at pg_create).
  *   - every call is asynchronous on the caller's hipStream_t; no hidden device syncs
- *     except where stated (pg_generate_text_greedy polls its finished-flag).
+ *     except where stated (pg_generate_text_greedy polls its finished-flag; pg_prefill reads ONE
+ *     4-byte flag back when it probes for a batch-constant negative prompt).
  *   - one handle per (process, GPU); a handle is not thread-safe.
  */
 #ifndef PLANGEN_HIP_H
@@ -177,8 +178,16 @@ typedef struct pg_timing {
     float  vq_ms;              /* whole last pg_vq_decode */
 } pg_timing;
 int pg_get_timing(pg_handle h, pg_timing* out);
-/* Tuning / measurement switches (defaults in parentheses); none changes results except where noted:
- *   time_attn (0)       per-launch HIP events around the decode-attention kernel (eager loop)
+/* Per-kernel-class sums of the last instrumented decode loop (pg_set_option("time_attn", 1); call pg_get_timing
+ * first: it collects the events).  cls 0..7: decode attention, QKV / O / gate|up(+SwiGLU) / down GEMMs, RMSNorm
+ * (+ split-K reduce + residual), gen_head, CFG sampler; *bytes_sum = algorithmic HBM bytes of the timed launches
+ * (weights once per launch; K/V once per launch).  Returns PG_ERR_ARG past the last class. */
+int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum, int* launches, double* bytes_sum);
+/* Tuning / measurement switches (defaults in parentheses), PER HANDLE; none changes results except where noted:
+ *   time_attn (0)       per-launch HIP events around every decode kernel class (eager loop); time_stride (1): every n-th step
+ *   rng_image_offset (0)  global index of this handle's image 0: prompt-sharded ranks sample exactly what one big batch would
+ *   allow_partial_weights (0)  run although required tensors were never loaded (they read as zeros)
+ *   stream_gemm (1)     decode GEMMs on the persistent weight-streaming kernel where instantiated
  *   use_graph (1)       replay the decode step as a hipGraph
  *   share_uncond (1)    prefill / store a batch-constant negative prompt once
  *   flash_prefill (1)   MFMA flash attention for prefill (0: per-query streaming kernel)

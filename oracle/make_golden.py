@@ -249,13 +249,111 @@ def golden_llama_and_sampling():
     print("generate ok", out.tolist())
 
 
+# Janus-Pro-1B WIDTH (hidden 2048, MLP 5632, 16 heads x 128, gen_head 2048 -> 16384) on 2 layers, small embedding
+# table and a small VQ so the oracle finishes in minutes: the shapes that select the bs=64 bench's kernel
+# instantiations (decode attention <bf16,7,4> with the shared-prefix branch, multi-tile flash prefill, tiled skinny
+# GEMMs NCK 8/4/16/11 + SwiGLU epilogue, rmsnorm NV=2, 256x256 prefill GEMMs with the SwiGLU epilogue).
+FULLW = dict(hidden=2048, inter=5632, n_layers=2, n_heads=16, head_dim=128, vocab=4096,
+             img_vocab=16384, img_dim=8, grid=24, gen_head_dim=2048, vq_ch=64,
+             vq_ch_mult=(1, 2, 2), vq_z=64, eos_id=7, pad_id=3,
+             vit_width=128, vit_layers=2, vit_heads=2, vit_mlp=256, vit_patch=8, vit_img=64)
+
+
+def fullw_prompts(cfg, B=64, L=256, seed=5):
+    """SURVEY 8d prompt shape: cond lengths U{160..256} left-padded to L, ONE 96-token negative prompt shared by
+    every uncond row; first real token BOS(=1)."""
+    g = torch.Generator().manual_seed(seed)
+    neg = torch.randint(8, cfg.vocab, (96,), generator=g).tolist()
+    neg[0] = 1
+    cond = []
+    for b in range(B):
+        n = int(torch.randint(160, L + 1, (1,), generator=g))
+        if b == 0:
+            n = L                      # one row without padding
+        row = torch.randint(8, cfg.vocab, (n,), generator=g).tolist()
+        row[0] = 1
+        cond.append(row)
+    return cond, neg
+
+
+@torch.no_grad()
+def golden_full_width(T=48):
+    """VERDICT r1 task 1: full-width fixture, 128 CFG rows (64 pairs), L = 256, T teacher-forceable decode steps,
+    driven by the installed transformers LlamaModel exactly like plangen_base.py:567-607 (greedy parity mode)."""
+    torch.set_num_threads(8)
+    cfg = R.OracleCfg(**FULLW)
+    W = R.make_weights(cfg, seed=3)
+    cond, neg = fullw_prompts(cfg)
+    ids, mask = R.t2i_infer_collate_batch(cond, neg, cfg.pad_id, cfg.img_tokens)
+    Rr, L = ids.shape
+    assert (Rr, L) == (128, 256)
+    model = hf_llama(cfg, W)
+    emb_layer = model.get_input_embeddings()
+    inputs_embeds = emb_layer(ids.long())
+    tokens = torch.zeros((Rr // 2, T), dtype=torch.int)
+    hid_rows = [0, 1, 64, 65, 126, 127]
+    img_full = [0, 63]
+    steps_full = [0, 1, 2, T - 1]
+    gvocab = torch.Generator().manual_seed(17)
+    vsel = torch.randperm(cfg.img_vocab, generator=gvocab)[:128].sort().values
+    last_hidden, top_v, top_i, sel_logits, full_logits = [], [], [], [], {}
+    prefill_hidden = None
+    outputs = None
+    for i in range(T):
+        outputs = model(inputs_embeds=inputs_embeds, attention_mask=mask, use_cache=True,
+                        past_key_values=outputs.past_key_values if i != 0 else None)
+        hidden_states = outputs.last_hidden_state
+        if i == 0:
+            prefill_hidden = hidden_states.clone()
+        h_last = hidden_states[:, -1, :]
+        last_hidden.append(h_last[hid_rows].clone())
+        logits = R.gen_head(W, h_last)
+        logit_cond, logit_uncond = logits[0::2, :], logits[1::2, :]
+        logits = logit_uncond + 5.0 * (logit_cond - logit_uncond)
+        tv, ti = logits.topk(4, dim=-1)
+        top_v.append(tv.clone()); top_i.append(ti.int().clone())
+        sel_logits.append(logits[:, vsel].clone())
+        if i in steps_full:
+            full_logits[i] = logits[img_full].clone()
+        next_token = torch.argmax(logits, dim=-1, keepdim=True)
+        tokens[:, i] = next_token.squeeze(-1)
+        next_token = torch.cat([next_token.unsqueeze(1), next_token.unsqueeze(1)], dim=1).view(-1)
+        inputs_embeds = R.prepare_gen_img_embeds(W, next_token).unsqueeze(1)
+        print("  full-width reference step", i, flush=True)
+    top_v = torch.stack(top_v); top_i = torch.stack(top_i); sel_logits = torch.stack(sel_logits)
+
+    # the restatement must reproduce the transformers-driven loop at this width too
+    mine_tok, mine_logits = R.sample_image(W, cfg, R.embed_tokens(W, ids), mask, 5.0, n_tokens=T, return_logits=True)
+    assert torch.equal(mine_tok, tokens)
+    err = (mine_logits[:, :, vsel] - sel_logits).abs().max().item()
+    assert err < 2e-3, err
+    mv, mi = mine_logits.topk(4, dim=-1)
+    assert torch.equal(mi[..., 0].int(), top_i[..., 0])
+
+    pos_sel = sorted(set(list(range(0, L, 16)) + list(range(L - 8, L))))
+    ph = prefill_hidden[hid_rows][:, pos_sel]                       # [6, P, H]
+    pad = (L - mask[:, :L].sum(-1)).int()
+    np.savez_compressed(os.path.join(OUT, "sample_image_fullwidth.npz"),
+                        ids=ids.numpy().astype(np.int16), pad=pad.numpy(), tokens=tokens.numpy(),
+                        hid_rows=np.array(hid_rows), pos_sel=np.array(pos_sel), prefill_hidden=ph.numpy(),
+                        prefill_last=prefill_hidden[:, -1].numpy(), last_hidden=torch.stack(last_hidden).numpy(),
+                        top_v=top_v.numpy(), top_i=top_i.numpy(), vsel=vsel.numpy().astype(np.int32), sel_logits=sel_logits.numpy(),
+                        img_full=np.array(img_full), steps_full=np.array(steps_full),
+                        full_logits=torch.stack([full_logits[i] for i in steps_full]).numpy(), wsum=wsum(W))
+    print("full-width sample_image ok; oracle-vs-transformers logits err", err)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "fullwidth":
+        golden_full_width()
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     golden_projector()
     golden_vq_tiny()
     golden_llama_and_sampling()
     golden_vq_full()
+    golden_full_width()
 
 
 if __name__ == "__main__":

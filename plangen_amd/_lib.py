@@ -52,6 +52,7 @@ SYMBOLS = [
     ("pg_vq_encode", C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P]),
     ("pg_vision_encode", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
     ("pg_get_timing", C.c_int, [_P, C.POINTER(pg_timing)]),
+    ("pg_get_class_timing", C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("pg_set_option", C.c_int, [_P, C.c_char_p, C.c_int64]),
     ("pg_device_bytes", C.c_int64, [_P]),
     ("pg_debug_read", C.c_int, [_P, C.c_char_p, C.c_int, _P, C.c_int64, _P]),

@@ -104,6 +104,7 @@ struct pg_engine {
     float* cfg_pv = nullptr; int* cfg_pi = nullptr;              // sampler stage-1 winners
     SampleParams* d_sparams = nullptr; TextParams* d_tparams = nullptr;   // per-call parameters the graphs read from HBM
     int32_t *d_out_tok = nullptr, *d_force_tok = nullptr; uint8_t* d_force_mask = nullptr; int64_t* d_text_out = nullptr;
+    int rng_image_offset = 0;                                    // pg_set_option("rng_image_offset", lo): this rank's first image in the global batch
     PgTune tune;                                                 // per-handle tuning knobs (pg_set_option)
     int tune_epoch = 0;                                          // bumped by every option that changes what a captured graph contains
     void* kv = nullptr;
@@ -126,7 +127,22 @@ struct pg_engine {
     hipGraphExec_t gexec_txt = nullptr; std::vector<int64_t> gkey_txt;      // text-decode step (lm_head + argmax + stack)
     void drop_graphs() { if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; } if (gexec_txt) { (void)hipGraphExecDestroy(gexec_txt); gexec_txt = nullptr; } }
     bool use_graph = true; bool time_attn = false; bool fuse_rope = true; bool force_swiglu = true; bool gn_fuse = true; int cu_split = 0;
-    std::vector<hipEvent_t> attn_ev; size_t attn_ev_used = 0; std::vector<double> attn_ev_bytes;
+    // per-kernel-class HIP-event timing of the decode loop (eager instrumented pass, pg_set_option("time_attn", 1)):
+    // one event pair per launch group on the launch stream, on every ``time_stride``-th decode step
+    enum { TC_ATTN = 0, TC_QKV, TC_O, TC_GU, TC_DOWN, TC_NORM, TC_HEAD, TC_SAMPLE, TC_N };
+    std::vector<hipEvent_t> tc_ev; size_t tc_used = 0; std::vector<std::pair<int, double>> tc_meta; int time_stride = 1;
+    double tc_ms[TC_N] = {}, tc_bytes[TC_N] = {}; int tc_launches[TC_N] = {};
+    bool tc_on = false; hipStream_t tc_stream = nullptr;
+    void tic(hipStream_t s) {
+        if (!tc_on) return;
+        while (tc_ev.size() < tc_used + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { tc_on = false; return; } tc_ev.push_back(e); }
+        (void)hipEventRecord(tc_ev[tc_used], s);
+    }
+    void toc(hipStream_t s, int cls, double bytes) {
+        if (!tc_on || tc_ev.size() < tc_used + 2) return;
+        (void)hipEventRecord(tc_ev[tc_used + 1], s);
+        tc_meta.emplace_back(cls, bytes); tc_used += 2;
+    }
     pg_timing timing{};
     bool have_decode_t = false, have_prefill_t = false, have_vq_t = false;
     int S_last = 1; long slab_last = 0;
@@ -546,7 +562,7 @@ void pg_engine::destroy() {
     if (stage_dev) (void)hipFree(stage_dev);
     for (int i = 0; i < 2; ++i) { if (h_stage2[i]) (void)hipHostFree(h_stage2[i]); if (ev_stage[i]) (void)hipEventDestroy(ev_stage[i]); }
     if (h_flag) (void)hipHostFree(h_flag);
-    for (hipEvent_t e : attn_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : tc_ev) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {ev_in, ev_out, ev_t0, ev_t1, ev_p0, ev_p1, ev_v0, ev_v1, ev_fork, ev_join};
     if (istream2) (void)hipStreamDestroy(istream2);
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -706,19 +722,25 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
     const bool sk = mode == 0;
     int S_pend = 0; long slab_pend = 0;
     const float scale = 1.0f / sqrtf(128.0f);
+    tc_on = time_attn && mode == 0 && (n_dec_host % (time_stride > 0 ? time_stride : 1)) == 0;
+    const double wb = (double)esz;                                  // weight bytes per element
+    auto norm_bytes = [&](int S) { return (double)M * Hh * (4.0 * (S + 2) + wb); };   // x + S slabs read, x written (S > 0), xn written
     for (int li = 0; li < cfg.n_layers; ++li) {
         const Layer& ly = layers[li];
+        tic(s);
         launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);
+        toc(s, TC_NORM, norm_bytes(S_pend));
+        tic(s);
         gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk, ly.wqkv_t);
-        const bool timed = time_attn && mode == 0 && attn_ev_used + 2 <= attn_ev.size();
+        toc(s, TC_QKV, 3.0 * HDm * Hh * wb);
         if (mode == 0 && fuse_rope) {
-            if (timed) (void)hipEventRecord(attn_ev[attn_ev_used], s);
+            tic(s);
             launch_attn_decode_fused<T>(s, part, S_last, slab_last, (T*)obuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), M,
                                         cfg.n_heads, slots, max_pos, scale);
         } else {
             launch_rope_kv<T>(s, part, S_last, slab_last, (T*)qbuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), mode, M,
                               cfg.n_heads, slots, max_pos);
-            if (timed) (void)hipEventRecord(attn_ev[attn_ev_used], s);
+            tic(s);
             bool done = false;
             if constexpr (std::is_same<T, bf16>::value) {
                 if (mode == 1 && flash_prefill) {
@@ -730,16 +752,19 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
             if (!done)
                 launch_attn<T>(s, (const T*)qbuf, (T*)obuf, (const T*)kc(li), (const T*)vc(li), seq(), mode, M, cfg.n_heads, slots, scale);
         }
-        if (timed) {
-            (void)hipEventRecord(attn_ev[attn_ev_used + 1], s);
+        if (tc_on) {
             double keys = shared_len;       // the shared uncond prompt is read from HBM once per launch
             for (int r = 0; r < R; ++r) keys += (double)(h_len[h_len_off + r] + n_dec_host + 1) - ((shared_len > 0 && (r & 1)) ? shared_len : 0);
-            attn_ev_bytes.push_back(keys * cfg.n_heads * 128 * 2 * (double)esz);
-            attn_ev_used += 2;
+            toc(s, TC_ATTN, keys * cfg.n_heads * 128 * 2 * (double)esz);
         }
+        tic(s);
         gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk, ly.wo_t);
+        toc(s, TC_O, (double)Hh * HDm * wb);
+        tic(s);
         launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);
+        toc(s, TC_NORM, norm_bytes(S_last));
         bool fused = false;
+        tic(s);
         if constexpr (std::is_same<T, bf16>::value) {
             // decode: SwiGLU gate fused into the gate|up GEMM epilogue (S = 1, no slab, no extra kernel)
             if (sk && M <= 512 && Hh % 128 == 0 && (force_swiglu || skinny_pick_splits(2 * I, Hh, M) == 1))   // fused wins at every M (B=4/8/16: -2..3 % loop time)
@@ -757,10 +782,16 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
             gemm_llm<T>(s, (const T*)xn, (const T*)ly.wgu, M, 2 * I, Hh, sk, ly.wgu_t);
             launch_silu_mul<T>(s, part, S_last, slab_last, (T*)hbuf, M, I);
         }
+        toc(s, TC_GU, 2.0 * I * Hh * wb);
+        tic(s);
         gemm_llm<T>(s, (const T*)hbuf, (const T*)ly.wd, M, Hh, I, sk, ly.wd_t);
+        toc(s, TC_DOWN, (double)Hh * I * wb);
         S_pend = S_last; slab_pend = slab_last;
     }
+    tic(s);
     launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps);
+    toc(s, TC_NORM, norm_bytes(S_pend));
+    tc_on = false;
 }
 
 int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtype, const int32_t* pad_len, int R_, int L_,
@@ -911,15 +942,17 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     sa.force_tok = d_force_tok; sa.force_mask = d_force_mask; sa.out_tok = d_out_tok; sa.logits_out = logits_out;
     sa.embed_table = gen_table; sa.H = Hh; sa.B_total = B;
     auto sample = [&](hipStream_t st, const LaneDef& L) {
+        tc_on = time_attn && (n_dec_host % (time_stride > 0 ? time_stride : 1)) == 0;
+        tic(st);
         if (bf) head_logits<bf16>(st, (const bf16*)hfin, R); else head_logits<float>(st, (const float*)hfin, R);
+        toc(st, TC_HEAD, ((double)G * Hh + (double)cfg.img_vocab * G) * (double)esz);
         sa.logits_partial = part; sa.S = S_last; sa.slab = slab_last; sa.x = x; sa.n_dec = d_ndec; sa.b_off = L.r0 / 2;
+        tic(st);
         launch_cfg_sample(st, sa, R / 2, cfg_pv, cfg_pi);
+        toc(st, TC_SAMPLE, (double)S_last * R * cfg.img_vocab * 4.0);
+        tc_on = false;
     };
-    if (time_attn) {
-        const size_t need = (size_t)2 * cfg.n_layers * T * nl;
-        while (attn_ev.size() < need) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); attn_ev.push_back(e); }
-        attn_ev_used = 0; attn_ev_bytes.clear();
-    }
+    if (time_attn) { tc_used = 0; tc_meta.clear(); }
     hipStream_t ws = s;
     if (graph || nl == 2) {      // graphs cannot be captured on the legacy default stream: hop to our own
         HIPCHK(hipEventRecord(ev_in, s));
@@ -945,7 +978,7 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     HIPCHK(hipEventRecord(ev_t0, ws));
     {   // per-call parameters and the caller's forcing tensors -> library-owned device memory (what the graph reads)
         SampleParams sp{}; sp.cfg_weight = cfgw; sp.temperature = temp; sp.seed = seed; sp.T = T;
-        sp.has_force = force_tok != nullptr; sp.has_mask = force_mask != nullptr;
+        sp.has_force = force_tok != nullptr; sp.has_mask = force_mask != nullptr; sp.img_off = rng_image_offset;
         launch_set_sample_params(ws, d_sparams, sp);
         if (force_tok) HIPCHK(hipMemcpyAsync(d_force_tok, force_tok, (size_t)B * T * 4, hipMemcpyDeviceToDevice, ws));
         if (force_mask) HIPCHK(hipMemcpyAsync(d_force_mask, force_mask, (size_t)B * T, hipMemcpyDeviceToDevice, ws));
@@ -1316,16 +1349,17 @@ int pg_engine::fetch_timing() {
     if (have_decode_t) { HIPCHK(hipEventSynchronize(ev_t1)); HIPCHK(hipEventElapsedTime(&timing.decode_ms, ev_t0, ev_t1)); have_decode_t = false; }
     if (have_prefill_t) { HIPCHK(hipEventSynchronize(ev_p1)); HIPCHK(hipEventElapsedTime(&timing.prefill_ms, ev_p0, ev_p1)); have_prefill_t = false; }
     if (have_vq_t) { HIPCHK(hipEventSynchronize(ev_v1)); HIPCHK(hipEventElapsedTime(&timing.vq_ms, ev_v0, ev_v1)); have_vq_t = false; }
-    if (attn_ev_used) {
-        float sum = 0.f; double by = 0;
-        for (size_t i = 0; i + 1 < attn_ev_used; i += 2) {
+    if (tc_used) {
+        for (int c = 0; c < TC_N; ++c) { tc_ms[c] = 0; tc_bytes[c] = 0; tc_launches[c] = 0; }
+        HIPCHK(hipEventSynchronize(tc_ev[tc_used - 1]));
+        for (size_t i = 0; i + 1 < tc_used; i += 2) {
             float ms = 0.f;
-            HIPCHK(hipEventSynchronize(attn_ev[i + 1]));
-            HIPCHK(hipEventElapsedTime(&ms, attn_ev[i], attn_ev[i + 1]));
-            sum += ms; by += attn_ev_bytes[i / 2];
+            HIPCHK(hipEventElapsedTime(&ms, tc_ev[i], tc_ev[i + 1]));
+            const int c = tc_meta[i / 2].first;
+            tc_ms[c] += ms; tc_bytes[c] += tc_meta[i / 2].second; tc_launches[c]++;
         }
-        timing.attn_ms_sum = sum; timing.attn_launches = (int)(attn_ev_used / 2); timing.attn_bytes_sum = by;
-        attn_ev_used = 0;
+        timing.attn_ms_sum = (float)tc_ms[TC_ATTN]; timing.attn_launches = tc_launches[TC_ATTN]; timing.attn_bytes_sum = tc_bytes[TC_ATTN];
+        tc_used = 0;
     }
     return PG_OK;
 }
@@ -1432,9 +1466,21 @@ int pg_get_timing(pg_handle h, pg_timing* out) {
     *out = h->timing;
     return rc;
 }
+int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum, int* launches, double* bytes_sum) {
+    static const char* const names[pg_engine::TC_N] = {"decode_attention", "decode_gemm_qkv", "decode_gemm_o", "decode_gemm_gate_up_swiglu",
+                                                       "decode_gemm_down", "decode_rmsnorm", "decode_gen_head", "decode_cfg_sampler"};
+    if (!h || cls < 0 || cls >= pg_engine::TC_N) return PG_ERR_ARG;
+    if (name) *name = names[cls];
+    if (ms_sum) *ms_sum = h->tc_ms[cls];
+    if (launches) *launches = h->tc_launches[cls];
+    if (bytes_sum) *bytes_sum = h->tc_bytes[cls];
+    return PG_OK;
+}
 int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!h || !key) return PG_ERR_ARG;
     if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
+    if (!strcmp(key, "rng_image_offset")) { h->rng_image_offset = (int)value; return PG_OK; }
+    if (!strcmp(key, "time_stride")) { h->time_stride = value > 0 ? (int)value : 1; return PG_OK; }
     if (!strcmp(key, "allow_partial_weights")) { h->allow_partial = value != 0; return PG_OK; }
     if (!strncmp(key, "split_target_", 13)) {
         (key[13] == 's' ? h->tune.split_small : key[13] == 'm' ? h->tune.split_mid : h->tune.split_big) = (int)value;

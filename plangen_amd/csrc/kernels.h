@@ -137,7 +137,7 @@ void launch_bias_f32(hipStream_t s, const float* partial, int S, long slab, cons
 // Per-call sampling parameters live in DEVICE memory (written by a 1-thread kernel at the top of
 // pg_decode_image_tokens), so the captured decode-step graph depends on shapes only and is replayed
 // across calls with different seeds / temperatures / caller buffers.
-struct SampleParams { float cfg_weight, temperature; uint64_t seed; int32_t T, has_force, has_mask, pad; };
+struct SampleParams { float cfg_weight, temperature; uint64_t seed; int32_t T, has_force, has_mask, img_off; };   // img_off: global index of this engine's image 0 (prompt-sharded runs draw the same noise as one big batch)
 struct SampleArgs {
     const float* logits_partial; int S; long slab; const float* bias; int V;
     const SampleParams* p;

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void cfg_scan_kernel(SampleArgs a, float* __re
         float mixed = u + cfg_weight * (c - u);
         if (a.logits_out) a.logits_out[((long)step * B + bg) * a.V + v] = mixed;
         if (temperature > 0.f) {
-            const float uu = rng_uniform(seed, (uint64_t)bg * 1000003ull + step, v);
+            const float uu = rng_uniform(seed, (uint64_t)(bg + a.p->img_off) * 1000003ull + step, v);
             mixed = mixed * invT - __logf(-__logf(uu));
         }
         if (mixed > best) { best = mixed; bi = v; }

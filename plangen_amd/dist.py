@@ -3,7 +3,7 @@
 The path shards over prompts: images are independent, a CFG pair (rows 2k, 2k+1) stays on
 one rank, weights are replicated.  There is no collective inside the 576-step loop: rank 0
 broadcasts the collated ids/mask once per batch (RCCL over xGMI; ~0.5 MB), every rank
-generates its contiguous slice, tokens / images are all-gathered at the end (2.3 KB/img
+generates its contiguous slice, tokens / images are gathered to rank 0 at the end (2.3 KB/img
 of tokens).  The reference's equivalent is accelerate's dataloader sharding with no gather
 (plangen_base.py:994).  Backend: ``nccl`` (= RCCL) on GPUs, ``gloo`` in the CPU tests.
 """
@@ -53,19 +53,40 @@ def broadcast_prompts(ids: Optional[torch.Tensor], mask: Optional[torch.Tensor],
     return ids_d[2 * lo:2 * hi].contiguous(), mask_d[2 * lo:2 * hi].contiguous(), lo, hi, B
 
 
-def gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
-    """All-gather per-image rows (tokens [b, T] or images [b, 3, S, S]) back into batch order."""
-    rank, ws = world()
-    if ws == 1:
-        return local
+def _padded(local: torch.Tensor, n_total: int, ws: int) -> torch.Tensor:
     per = (n_total + ws - 1) // ws
-    pad_shape = (per,) + tuple(local.shape[1:])
-    buf = torch.zeros(pad_shape, dtype=local.dtype, device=local.device)
+    buf = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local
-    outs = [torch.empty_like(buf) for _ in range(ws)]
-    dist.all_gather(outs, buf)
+    return buf
+
+
+def _unpad(outs, n_total: int, ws: int) -> torch.Tensor:
     parts = []
     for r in range(ws):
         lo, hi = shard_range(n_total, ws, r)
         parts.append(outs[r][: hi - lo])
     return torch.cat(parts, dim=0)
+
+
+def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """Gather per-image rows (tokens [b, T] or images [b, 3, S, S]) to rank ``dst`` in batch order; other ranks
+    get None.  A gather, not an all-gather: only the rank that writes the results needs them (2.3 KB of tokens per
+    image, but 1.7 MB per image for pixels)."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    buf = _padded(local, n_total, ws)
+    outs = [torch.empty_like(buf) for _ in range(ws)] if rank == dst else None
+    dist.gather(buf, outs, dst=dst)
+    return _unpad(outs, n_total, ws) if rank == dst else None
+
+
+def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """The same rows on EVERY rank (only for callers that really need them everywhere)."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    buf = _padded(local, n_total, ws)
+    outs = [torch.empty_like(buf) for _ in range(ws)]
+    dist.all_gather(outs, buf)
+    return _unpad(outs, n_total, ws)

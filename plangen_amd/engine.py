@@ -121,6 +121,18 @@ class Engine:
         self._check(self.lib.pg_get_timing(self.h, C.byref(t)), "pg_get_timing")
         return {k: getattr(t, k) for k, _ in t._fields_}
 
+    def class_timing(self) -> dict:
+        """Per-kernel-class sums of the last instrumented decode loop (after ``timing()``)."""
+        out = {}
+        cls = 0
+        while True:
+            name, ms, n, by = C.c_char_p(), C.c_double(), C.c_int(), C.c_double()
+            if self.lib.pg_get_class_timing(self.h, cls, C.byref(name), C.byref(ms), C.byref(n), C.byref(by)) != 0:
+                break
+            out[name.value.decode()] = {"ms_sum": ms.value, "launches": n.value, "bytes_sum": by.value}
+            cls += 1
+        return out
+
     # ------------------------------------------------------------------ weights
     def load_tensors(self, sd: Dict[str, torch.Tensor]) -> Tuple[int, list]:
         """Hand tensors to ``pg_load_tensor`` by their reference state_dict names (HF Janus-Pro-1B keys,

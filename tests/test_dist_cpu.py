@@ -6,7 +6,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from plangen_amd.dist import broadcast_prompts, gather_rows, shard_range
+from plangen_amd.dist import all_gather_rows, broadcast_prompts, gather_rows, shard_range
 
 
 def test_shard_range_partitions():
@@ -34,10 +34,15 @@ def _worker(rank, ws, port, B, L, T, ret):
     assert torch.equal(my_ids, ids[2 * lo:2 * hi])            # CFG pairs stay together
     # stand-in for generation: tokens derived from the cond row only
     toks = my_ids[0::2, :T].clone()
-    allt = gather_rows(toks, B)
-    assert torch.equal(allt, ids[0::2, :T])
+    allt = gather_rows(toks, B)                                # a gather to rank 0, not an all-gather
+    if rank == 0:
+        assert torch.equal(allt, ids[0::2, :T])
+    else:
+        assert allt is None
     imgs = gather_rows(my_ids[0::2, :3].float().view(-1, 3, 1, 1), B)
-    assert torch.equal(imgs.view(B, 3), ids[0::2, :3].float())
+    if rank == 0:
+        assert torch.equal(imgs.view(B, 3), ids[0::2, :3].float())
+    assert torch.equal(all_gather_rows(toks, B), ids[0::2, :T])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -45,3 +50,34 @@ def _worker(rank, ws, port, B, L, T, ret):
 def test_broadcast_and_gather_world2():
     port = _free_port()
     mp.spawn(_worker, args=(2, port, 5, 6, 4, None), nprocs=2, join=True)
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_launcher_spawns_ranks_itself():
+    """`python bench.py --gpus N` with no WORLD_SIZE: the parent starts N rank processes (env rendezvous on
+    127.0.0.1), relays ONE JSON line from rank 0 and exits 0 (dry run: gloo, no GPU)."""
+    rc, out, err = _bench("--gpus", "2", "--launch-check", "--global-batch", "6")
+    assert rc == 0, err
+    assert out == {"launch_check": "ok", "world": 2, "global_images": 6, "images_rank0": 3, "backend": "gloo"}
+    rc, out, err = _bench("--gpus", "3", "--launch-check", "--batch", "4")
+    assert rc == 0 and out["world"] == 3 and out["global_images"] == 12, err
+
+
+def test_bench_refuses_mislabelled_world_size():
+    """Launched by torchrun with a world size that is not --gpus: non-zero exit, no JSON line."""
+    rc, out, err = _bench("--gpus", "4", "--launch-check", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0",
+                                                                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    assert rc != 0 and out is None and "WORLD_SIZE" in err
