@@ -336,6 +336,7 @@ int pg_engine::build_vision() {
     if (bf && (P % 64 || (3 * ps * ps) % 64)) FAIL(PG_ERR_ARG, "bf16 mode needs patch count and 3*patch^2 to be multiples of 64");
     const std::string VT = "vision_model.vision_tower.";
     TRY(alloc_lin(VT + "patch_embed.proj", vit_patch, C, 3 * ps * ps));
+    slot_shape(VT + "patch_embed.proj.weight", {C, 3, ps, ps});          // a Conv2d weight in the checkpoint
     TRY(dalloc(&vit_pos, (size_t)P * C * 4));
     add_slot(VT + "pos_embed", vit_pos, K_F32, (long)P * C);
     vit_blocks.resize(cfg.vit_layers);
