@@ -187,7 +187,9 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *   time_attn (0)       per-launch HIP events around every decode kernel class (eager loop); time_stride (1): every n-th step
  *   rng_image_offset (0)  global index of this handle's image 0: prompt-sharded ranks sample exactly what one big batch would
  *   allow_partial_weights (0)  run although required tensors were never loaded (they read as zeros)
- *   stream_gemm (1)     decode GEMMs on the persistent weight-streaming kernel where instantiated
+ *   stream_gemm (-1 auto)  bit mask of the decode GEMM classes on the v4 kernel (x tile by LDS-DMA): 1 wide-N slabs, 2 narrow-N
+ *                       slabs, 4 SwiGLU gate|up, 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue; 0 = v3 everywhere
+ *   wt_store (0)        v3 split-K slabs with write-through (sc1) stores
  *   use_graph (1)       replay the decode step as a hipGraph
  *   share_uncond (1)    prefill / store a batch-constant negative prompt once
  *   flash_prefill (1)   MFMA flash attention for prefill (0: per-query streaming kernel)

@@ -45,6 +45,71 @@ extern "C" int pg_bench_skinny(int M, int N, int K, int variant, int S, int iter
     return rc;
 }
 
+__global__ void maxdiff_kernel(const float* a, const float* b, long n, float* out);
+// Correctness screen for a decode-GEMM variant: out(variant, tiled or row-major W as it expects) vs the v1 kernel
+// on the same random operands, split-K slabs reduced; returns max |diff| and max |ref|.
+__global__ void reduce_slabs_kernel(const float* p, int S, long slab, float* o) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < slab; i += (long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += p[(long)s * slab + i];
+        o[i] = a;
+    }
+}
+extern "C" int pg_bench_skinny_verify(int M, int N, int K, int variant, int S, int tiled, int reps, float* maxdiff, float* maxref) {
+    bf16 *x, *W, *Wt; float *o0, *o1, *r0, *r1, *md;
+    hipMalloc((void**)&x, (long)M * K * 2); hipMalloc((void**)&W, (long)N * K * 2); hipMalloc((void**)&Wt, (long)N * K * 2);
+    hipMalloc((void**)&o0, (long)S * M * N * 4); hipMalloc((void**)&o1, (long)S * M * N * 4);
+    hipMalloc((void**)&r0, (long)M * N * 4); hipMalloc((void**)&r1, (long)M * N * 4); hipMalloc((void**)&md, 8);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(256), dim3(256), 0, 0, x, (long)M * K, 3u);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
+    launch_tile_weights(0, W, Wt, N, K);
+    hipMemset(md, 0, 8);
+    int rc = 0;
+    launch_gemm_skinny_variant(0, 1, x, W, o0, M, N, K, S);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1024), dim3(256), 0, 0, o0, S, (long)M * N, r0);
+    hipMemset(r1, 0, (long)M * N * 4);
+    hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, 0, r0, r1, (long)M * N, md + 1);       // max |ref|
+    for (int rep = 0; rep < reps; ++rep) {
+        hipMemset(o1, 0xff, (long)S * M * N * 4);
+        if (!launch_gemm_skinny_variant(0, variant, x, tiled ? Wt : W, o1, M, N, K, S)) { rc = -1; break; }
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1024), dim3(256), 0, 0, o1, S, (long)M * N, r1);
+        hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, 0, r0, r1, (long)M * N, md);
+    }
+    hipDeviceSynchronize();
+    if (hipGetLastError() != hipSuccess) rc = -2;
+    float h[2] = {0, 0}; hipMemcpy(h, md, 8, hipMemcpyDeviceToHost);
+    if (maxdiff) *maxdiff = h[0]; if (maxref) *maxref = h[1];
+    hipFree(x); hipFree(W); hipFree(Wt); hipFree(o0); hipFree(o1); hipFree(r0); hipFree(r1); hipFree(md);
+    return rc;
+}
+
+// Per-wave s_memtime stamps of ONE launch of a v4 variant (after warm-up launches on rotating weights):
+// stamps_host [nwaves][64] cycle counters; returns the number of waves, or < 0.
+extern unsigned long long* g_sk4_prof;
+extern "C" int pg_bench_sk4_profile(int M, int N, int K, int variant, int S, unsigned long long* stamps_host, int max_waves) {
+    const long wbytes = (long)N * K * 2;
+    const int nbuf = 8;
+    std::vector<bf16*> Ws(nbuf);
+    for (auto& p : Ws) { if (hipMalloc((void**)&p, wbytes) != hipSuccess) return -2; hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, p, (long)N * K, 7u); }
+    bf16* x; float* out; unsigned long long* prof;
+    hipMalloc((void**)&x, (long)M * K * 2); hipMalloc((void**)&out, (long)S * M * N * 4);
+    hipMalloc((void**)&prof, (size_t)max_waves * 64 * 8); hipMemset(prof, 0, (size_t)max_waves * 64 * 8);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(256), dim3(256), 0, 0, x, (long)M * K, 3u);
+    hipStream_t s; hipStreamCreate(&s);
+    int rc = 0;
+    for (int it = 0; it < nbuf; ++it) {
+        g_sk4_prof = it == nbuf - 1 ? prof : nullptr;
+        if (!launch_gemm_skinny_variant(s, variant, x, Ws[it], out, M, N, K, S)) { rc = -1; break; }
+    }
+    g_sk4_prof = nullptr;
+    hipStreamSynchronize(s);
+    if (hipGetLastError() != hipSuccess) rc = -2;
+    hipMemcpy(stamps_host, prof, (size_t)max_waves * 64 * 8, hipMemcpyDeviceToHost);
+    for (auto p : Ws) hipFree(p);
+    hipFree(x); hipFree(out); hipFree(prof); hipStreamDestroy(s);
+    return rc;
+}
+
 // Pure streaming read (calibration for the HBM-bound kernels): every block reads a contiguous
 // slice with 16-byte loads, UN loads in flight per lane, result folded into one word per block.
 template <bool NT>
@@ -65,7 +130,8 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const u32x4* __restric
     if (acc == 0x12345678u) out[blockIdx.x] = acc;
 }
 extern "C" int pg_bench_stream(long bytes, int blocks, int iters, int nt, float* us_out) {
-    const long total = 3 * bytes;                      // rotate through 3 regions (> Infinity Cache)
+    const int nreg = (int)((768L << 20) / bytes) + 2;     // rotate through > 768 MiB (Infinity Cache is 256 MiB)
+    const long total = nreg * bytes;
     char* buf; if (hipMalloc((void**)&buf, total) != hipSuccess) return -2;
     hipMemset(buf, 1, total);
     uint32_t* out; hipMalloc((void**)&out, blocks * 4);
@@ -74,7 +140,7 @@ extern "C" int pg_bench_stream(long bytes, int blocks, int iters, int nt, float*
     const long nvpb = bytes / 16 / blocks;
     for (int it = -3; it < iters; ++it) {
         if (it == 0) hipEventRecord(e0, s);
-        const u32x4* p = (const u32x4*)(buf + (long)((it + 3) % 3) * bytes);
+        const u32x4* p = (const u32x4*)(buf + (long)((it + 3) % nreg) * bytes);
         if (nt) hipLaunchKernelGGL(stream_read_kernel<true>, dim3(blocks), dim3(256), 0, s, p, nvpb, out);
         else hipLaunchKernelGGL(stream_read_kernel<false>, dim3(blocks), dim3(256), 0, s, p, nvpb, out);
     }

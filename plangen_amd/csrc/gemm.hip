@@ -17,6 +17,7 @@
 #include "kernels.h"
 
 #include "gemm_common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------- big MFMA GEMM
 #define BIG_BM 128
@@ -228,7 +229,7 @@ template void launch_gemm<bf16>(hipStream_t, const GemmA&, const bf16*, long, lo
 // instead of 32 scattered dword stores.  smem must hold MT*16 rows x (NW*16+4) floats.
 template <int MT, int NW>
 __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)[MT], float* __restrict__ o, int M, int N,
-                                                  int mbase, int nbase, int w, int g, int lr, int tid) {
+                                                  int mbase, int nbase, int w, int g, int lr, int tid, int wt = 0) {
     constexpr int LD = NW * 16 + 4, NTH = NW * 64, V4 = NW * 4;        // float4 per tile row
     float* t = (float*)smem;
     __syncthreads();                                   // every wave is done reading the x tiles
@@ -240,7 +241,13 @@ __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)
     for (int v = tid; v < MT * 16 * V4; v += NTH) {
         const int row = v / V4, c4 = (v % V4) * 4;
         const int m = mbase + row, n = nbase + c4;
-        if (m < M && n < N) __builtin_nontemporal_store(*(const f32x4*)(t + row * LD + c4), (f32x4*)(o + (long)m * N + n));
+        if (m < M && n < N) {
+            const f32x4 v4 = *(const f32x4*)(t + row * LD + c4);
+            float* p = o + (long)m * N + n;
+            // wt: write-through (sc1) -- the slab leaves this XCD's L2 while the kernel runs, not as dirty lines at the boundary
+            if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v4) : "memory");
+            else __builtin_nontemporal_store(v4, (f32x4*)p);
+        }
     }
 }
 
@@ -421,7 +428,7 @@ void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* o
 // indexed.  XDB: x tile double-buffered (2 blocks/CU at MT=8) or single-buffered (4 blocks/CU).
 template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
-                                                               float* __restrict__ out, int M, int N, int K) {
+                                                               float* __restrict__ out, int M, int N, int K, int wt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XB = MT * 16 * SK_ROWB, NTH = 64 * NW, BN = 16 * NW;
     constexpr int XV = (MT * 256 + NTH - 1) / NTH;                     // x vectors per thread per chunk
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
         }
     }
     if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid);
-    else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * BN, w, g, lr, tid);
+    else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * BN, w, g, lr, tid, wt);
 }
 template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false>
 static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
@@ -492,7 +499,7 @@ static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
     dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
-    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K, pg_tune->wt_store);
 }
 template <int D, bool XDB>
 static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
@@ -571,6 +578,242 @@ static bool sk3_prod(hipStream_t s, const bf16* x, const bf16* W, float* out, in
     return sk3_prod_nck<8, EPI>(s, x, W, out, M, N, K, S, nck);
 }
 
+
+// ------------------------------------------------------------------------------- skinny GEMM v4 ("stream")
+// Same block tile as v3 (BN = 16*NW columns, MT*16 rows, BK = 128, tiled W, W register ring of depth WD) but
+// the x tile never touches a VGPR: every 128-wide K chunk of the block's MT*16 rows is brought HBM/L2 -> LDS by
+// LDS-DMA (global_load_lds, 1 KiB per wave instruction) into a ring of XD chunk slots, XD-1 chunks AHEAD of
+// the MFMAs that read it.  v3 staged x through registers one chunk ahead: a block's every chunk then waited
+// for an L2 round trip (measured: x-tile loads = 3.6 of the qkv kernel's 15 us); here that latency sits under
+// XD-1 chunks of MFMA + W streaming, the xstore LDS writes and their staging registers are gone, and there is
+// ONE s_barrier per chunk (no vmcnt(0)/lgkmcnt(0) drain: raw s_barrier + counted vmcnt).
+//   LDS chunk slot: MT*16 rows x 256 B, no padding (the DMA writes 64 consecutive 16-byte slots per
+//   instruction = 4 rows); bank conflicts are avoided by permuting the SOURCE: slot s of row r holds logical
+//   16-byte chunk s ^ (r & 15), so the fragment read of lane (lr, g), k-step i is at
+//   row*256 + (((4i + g) ^ lr) << 4): 16 distinct slots per 16-lane group.
+//   Program order of VMEM ops per wave (all counted by hand, W loads by the compiler):
+//     prologue  X(0) .. X(XD-2), W(0) .. W(WD-1)
+//     chunk c   s_waitcnt vmcnt(A(c))  -> this wave's X(c) pieces have landed        (A = ops issued after X(c))
+//               s_barrier              -> every wave's X(c) pieces have landed, every wave is done reading X(c-1)
+//               issue X(c+XD-1) into the slot of X(c-1)
+//               MFMA on X(c), W(c)     (the compiler waits for W(c))
+//               issue W(c+WD) into W(c)'s registers
+constexpr int sk4_wait_count(int c, int NCK, int XD, int WD, int MT) {
+    int ops = 0, lastX[64] = {};
+    for (int p = 0; p < XD - 1 && p < NCK; ++p) { ops += MT; lastX[p] = ops; }
+    for (int p = 0; p < WD && p < NCK; ++p) ops += 4;
+    for (int it = 0; it < NCK; ++it) {
+        if (it == c) return ops - lastX[c];
+        if (it + XD - 1 < NCK) { ops += MT; lastX[it + XD - 1] = ops; }
+        if (it + WD < NCK) ops += 4;
+    }
+    return 0;
+}
+// ops issued after W(c)'s last load at the point of chunk c where the MFMAs start (after X(c+XD-1) was issued)
+constexpr int sk4_wait_count_w(int c, int NCK, int XD, int WD, int MT) {
+    int ops = 0, lastW[64] = {};
+    for (int p = 0; p < XD - 1 && p < NCK; ++p) ops += MT;
+    for (int p = 0; p < WD && p < NCK; ++p) { ops += 4; lastW[p] = ops; }
+    for (int it = 0; it < NCK; ++it) {
+        if (it + XD - 1 < NCK) ops += MT;
+        if (it == c) return ops - lastW[c];
+        if (it + WD < NCK) { ops += 4; lastW[it + WD] = ops; }
+    }
+    return 0;
+}
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_ > 63 ? 63 : N_) : "memory"); }   // 6-bit field: clamping only waits longer
+
+template <bool SWAP>
+__device__ __forceinline__ f32x4 sk4_mfma(const bf16x8& a, const bf16x8& wv, const f32x4& c) {
+    // SWAP: D = W . x^T -- the lane then holds 4 consecutive output COLUMNS of one row (16-byte epilogue stores)
+    if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, a, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wv, c, 0, 0, 0);
+}
+template <int MT, bool SWAP = false>
+__device__ __forceinline__ void sk4_mfma_chunk(const char* xt, int lr, int g, const bf16x8 (&wc)[4], f32x4 (&acc)[MT]) {
+    // A fragment (m-tile mt, k-step i): row mt*16 + lr, logical 16-byte chunk 4i + g, swizzled by lr
+    const char* rp = xt + lr * 256;
+    int so[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) so[i] = ((i * 4 + g) ^ lr) << 4;
+    if constexpr (MT == 1) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(rp + so[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[0] = sk4_mfma<SWAP>(a[i], wc[i], acc[0]);
+    } else {
+        constexpr int NP = MT / 2;
+        bf16x8 af[2][2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[0][h][i] = *(const bf16x8*)(rp + h * 4096 + so[i]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p + 1 < NP) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        af[(p + 1) & 1][h][i] = *(const bf16x8*)(rp + ((p + 1) * 2 + h) * 4096 + so[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * p] = sk4_mfma<SWAP>(af[p & 1][0][i], wc[i], acc[2 * p]);
+                acc[2 * p + 1] = sk4_mfma<SWAP>(af[p & 1][1][i], wc[i], acc[2 * p + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+// Epilogues for the swapped accumulator layout: lane (lr, g) holds out[row mt*16 + lr][n-tile column 4g .. 4g+3].
+// WT: write-through (sc1) stores -- the slab leaves the XCD's L2 while the kernel still runs instead of as dirty lines
+// at the kernel boundary (the boundary pays ~0.2-0.4 us per dirty MB).
+template <int MT, bool WT = false>
+__device__ __forceinline__ void sk4_store_direct(const f32x4 (&acc)[MT], float* __restrict__ o, int M, int N, int mbase, int ncol0, int g, int lr) {
+    const int n = ncol0 + g * 4;
+    if (n >= N) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mbase + mt * 16 + lr;
+        if (m < M) {
+            float* p = o + (long)m * N + n;
+            if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(acc[mt]) : "memory");
+            else __builtin_nontemporal_store(acc[mt], (f32x4*)p);
+        }
+    }
+}
+// SwiGLU: an n-tile is [8 gate | 8 up]: lanes g = 0,1 hold gate columns 4g..4g+3, lanes g + 2 the matching up columns
+template <int MT>
+__device__ __forceinline__ void sk4_store_swiglu_direct(const f32x4 (&acc)[MT], bf16* __restrict__ h, int M, int I, int mbase, int ntile, int g, int lr) {
+    const int col = ntile * 8 + (g & 1) * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = __shfl_xor(acc[mt][r], 32, 64);
+        const int m = mbase + mt * 16 + lr;
+        if (g < 2 && m < M && col < I) {
+            float hv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float gt = acc[mt][r]; hv[r] = (gt / (1.f + expf(-gt))) * u[r]; }
+            u32x2 pk; pk.x = pack_bf16x2(hv[0], hv[1]); pk.y = pack_bf16x2(hv[2], hv[3]);
+            *(u32x2*)(h + (long)m * I + col) = pk;
+        }
+    }
+}
+
+template <int C, int NCK, int XD, int WD, int MT, class F> __device__ __forceinline__ void sk4_static_for(F&& f) {
+    if constexpr (C < NCK) { f(std::integral_constant<int, C>{}); sk4_static_for<C + 1, NCK, XD, WD, MT>(f); }
+}
+
+// MS = 2: 8 waves per block, wave w = (n-tile w & 3, row half w >> 2): two waves per SIMD, so one wave's LDS fragment
+// reads run under the other's MFMAs (measured with 4 lock-stepped waves: reads and MFMAs of a chunk serialise,
+// ~1050 cycles per chunk instead of ~550).  Both row halves load the same W fragments (second one hits L1/L2).
+template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>      // ABL (bench only): 1 no x DMA / barriers, 2 no MFMA, 4 no stores
+__global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+                                                               float* __restrict__ out, int M, int N, int K, unsigned long long* prof) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MTW = MT / MS;                                     // m-tiles per wave
+    // tuning aid: per-wave s_memtime stamps (prof != nullptr only from the microbenchmark): 64 slots per wave
+    int pslot = 0;
+    unsigned long long* pw = prof ? prof + ((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (4 * MS) + (threadIdx.x >> 6)) * 64 : nullptr;
+    auto stamp = [&]() { if (pw && (threadIdx.x & 63) == 0 && pslot < 64) pw[pslot] = __builtin_readcyclecounter(); ++pslot; };
+    stamp();
+    constexpr int XB = MT * 16 * 256;                                // bytes per x chunk slot
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, lr = l & 15;
+    const int wn = w & 3, wm = w >> 2;
+    const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
+    const int ntile = blockIdx.x * 4 + wn, ntiles = (N + 15) / 16;
+    const bf16* wp = W + ((long)(ntile < ntiles ? ntile : ntiles - 1) * (K / SK_BK) + split * NCK) * 2048 + l * 8;
+    // x DMA: wave w owns pieces w*MTW .. w*MTW+MTW-1 of every chunk; piece q = rows 4q .. 4q+3
+    const bf16* xsrc[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int r = (w * MTW + j) * 4 + (l >> 4);
+        const int m = mbase + r;
+        xsrc[j] = x + (long)(m < M ? m : M - 1) * K + split * NCK * SK_BK + (((l & 15) ^ (r & 15)) << 3);
+    }
+    auto issueX = [&](int c) {
+        char* slot = smem + (c % XD) * XB + w * (MTW * 1024);
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) glds16(xsrc[j] + c * SK_BK, slot + j * 1024);
+    };
+    bf16x8 wr[WD][4];
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (!(ABL & 1)) {
+#pragma unroll
+        for (int c = 0; c < XD - 1 && c < NCK; ++c) issueX(c);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < WD && c < NCK; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[c][i] = __builtin_nontemporal_load((const bf16x8*)(wp + c * 2048 + i * 512));
+    asm volatile("" ::: "memory");
+    stamp();
+    sk4_static_for<0, NCK, XD, WD, MTW>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (!(ABL & 1)) {
+            if constexpr (ABL & 8) wait_vmcnt<0>(); else wait_vmcnt<sk4_wait_count(c, NCK, XD, WD, MTW)>();      // ABL 8 (bench): drain everything
+            stamp();
+            __builtin_amdgcn_s_barrier();
+            stamp();
+            if constexpr (c + XD - 1 < NCK) issueX(c + XD - 1);
+        }
+        asm volatile("" ::: "memory");
+        if (pw) { wait_vmcnt<sk4_wait_count_w(c, NCK, XD, WD, MTW)>(); stamp(); }      // profiling only: when did W(c) land?
+        if constexpr (!(ABL & 2)) sk4_mfma_chunk<MTW, (EPI >= 2)>(smem + (c % XD) * XB + wm * (MTW * 4096), lr, g, wr[c % WD], acc);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[0][0] += (float)wr[c % WD][i][0]; }
+        }
+        if constexpr (c + WD < NCK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wr[c % WD][i] = __builtin_nontemporal_load((const bf16x8*)(wp + (c + WD) * 2048 + i * 512));
+        }
+        asm volatile("" ::: "memory");
+        stamp();
+    });
+    if constexpr (ABL & 4) { if (acc[0][0] == 123.456f) out[tid] = acc[0][0]; return; }
+    const int mb = mbase + wm * MTW * 16;
+    if constexpr (EPI == 3) sk4_store_swiglu_direct<MTW>(acc, (bf16*)out, M, N / 2, mb, ntile, g, lr);
+    else if constexpr (EPI == 2) sk4_store_direct<MTW>(acc, out + (long)split * M * N, M, N, mb, ntile * 16, g, lr);
+    else if constexpr (EPI == 4) sk4_store_direct<MTW, true>(acc, out + (long)split * M * N, M, N, mb, ntile * 16, g, lr);
+    else if constexpr (EPI == 1) { static_assert(EPI != 1 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_swiglu<MT, 4>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid); }
+    else { static_assert(EPI != 0 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_tile<MT, 4>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid); }
+    if (pw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); }
+}
+unsigned long long* g_sk4_prof = nullptr;       // microbenchmark only
+template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
+static void launch_sk4(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+    constexpr int XL = XD * MT * 16 * 256, TL = MT * 16 * (4 * 16 + 4) * 4;
+    constexpr int LDS = XL > TL ? XL : TL;
+    auto kfn = gemm_sk4_kernel<MT, NCK, XD, WD, EPI, OCC, ABL, MS>;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+    dim3 grid((N + 63) / 64, S, (M + MT * 16 - 1) / (MT * 16)), block(256 * MS);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, Wt, out, M, N, K, g_sk4_prof);
+}
+template <int MT, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
+static bool sk4_nck(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+    const int nck = K / SK_BK / S;
+    if (nck * S * SK_BK != K || (N & 15)) return false;
+    switch (nck) {
+        case 2: launch_sk4<MT, 2, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 4: launch_sk4<MT, 4, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 8: launch_sk4<MT, 8, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 11: launch_sk4<MT, 11, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 16: launch_sk4<MT, 16, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 22: launch_sk4<MT, 22, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        default: return false;
+    }
+}
+
 void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
 // variant table for the microbenchmark (tools/skinny_sweep.py): returns BK (0 = unsupported)
 int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
@@ -588,12 +831,101 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         }
         case 50: return sk3_prod_nck<8, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W layout
         case 51: return sk3_prod_nck<4, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W, 64-row M blocks
+        // v4 (x by LDS-DMA): MT / x ring depth / W ring depth / min blocks per CU
+        case 70: return sk4_nck<4, 3, 2, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 71: return sk4_nck<4, 3, 3, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 72: return sk4_nck<4, 4, 3, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 73: return sk4_nck<4, 4, 4, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 74: return sk4_nck<8, 3, 3, 0, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 75: return sk4_nck<8, 4, 4, 0, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 76: return sk4_nck<4, 3, 3, 0, 3>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 77: return sk4_nck<2, 4, 3, 0, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        // ablations of v71 (MT 4, XD 3, WD 3) and v74 (MT 8): 1 no x, 2 no MFMA, 4 no stores
+        case 91: return sk4_nck<4, 3, 3, 0, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 92: return sk4_nck<4, 3, 3, 0, 2, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 93: return sk4_nck<4, 3, 3, 0, 2, 3>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 94: return sk4_nck<4, 3, 3, 0, 2, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 97: return sk4_nck<4, 3, 3, 0, 2, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 95: return sk4_nck<4, 3, 3, 0, 2, 5>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 96: return sk4_nck<4, 3, 3, 0, 2, 6>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 107: return sk4_nck<8, 3, 3, 0, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 170: return sk4_nck<2, 4, 3, 4, 4, 8>(s, x, W, out, M, N, K, S) ? 128 : 0;     // v160 with vmcnt(0) before every barrier
+        case 160: return sk4_nck<2, 4, 3, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 32-row blocks
+        case 161: return sk4_nck<1, 4, 3, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 16-row blocks
+        case 162: return sk4_nck<1, 4, 4, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 163: return sk4_nck<2, 4, 4, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 164: return sk4_nck<4, 4, 4, 4, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 150: return sk4_nck<8, 3, 3, 4, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;        // v123 with write-through stores
+        case 151: return sk4_nck<4, 3, 3, 4, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 64-row blocks, write-through stores
+        case 152: return sk4_nck<4, 3, 3, 2, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 64-row blocks, direct nt stores
+        // ablations of v123 (MT 8, XD 3, WD 3, direct stores)
+        case 141: return sk4_nck<8, 3, 3, 2, 1, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // no x
+        case 142: return sk4_nck<8, 3, 3, 2, 1, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;     // no MFMA
+        case 143: return sk4_nck<8, 3, 3, 2, 1, 3>(s, x, W, out, M, N, K, S) ? 128 : 0;     // no x, no MFMA
+        case 144: return sk4_nck<8, 3, 3, 2, 1, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;     // no stores
+        case 145: return sk4_nck<8, 3, 3, 2, 1, 5>(s, x, W, out, M, N, K, S) ? 128 : 0;     // no x, no stores
+        case 146: return sk4_nck<8, 3, 3, 2, 1, 6>(s, x, W, out, M, N, K, S) ? 128 : 0;     // no MFMA, no stores
+        case 147: return sk4_nck<8, 3, 3, 2, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;     // W only
+        // 8 waves per block (two row halves): LDS reads of one wave under the MFMAs of the other
+        case 130: return sk4_nck<8, 3, 3, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 131: return sk4_nck<8, 4, 4, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 132: return sk4_nck<8, 3, 2, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 133: return sk4_nck<8, 3, 6, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 134: return sk4_nck<4, 3, 3, 2, 2, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;    // 64-row blocks, 8 waves of 2 m-tiles
+        case 120: return sk4_nck<8, 3, 8, 0, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // deep W ring, transposed stores
+        case 121: return sk4_nck<8, 3, 8, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // deep W ring, direct 16-byte stores
+        case 122: return sk4_nck<8, 4, 8, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // + x ring 4
+        case 123: return sk4_nck<8, 3, 3, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // shallow W ring, direct stores
+        case 124: return sk4_nck<4, 3, 8, 2, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;     // 64-row blocks, deep W, direct stores
+        case 125: return sk4_nck<4, 4, 6, 2, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 126: return sk4_nck<8, 3, 5, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 108: return sk4_nck<8, 3, 6, 0, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;     // W only, ring 6
+        case 109: return sk4_nck<8, 3, 8, 0, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;     // W only, ring 8
+        case 110: return sk4_nck<8, 3, 2, 0, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;     // W only, ring 2
+        case 104: return sk4_nck<8, 3, 3, 0, 1, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 80: return sk4_nck<4, 3, 3, 1, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;            // SwiGLU epilogue (S = 1)
+        case 81: return sk4_nck<8, 3, 3, 1, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
         default: return 0;
     }
 }
 
+// v4 ("stream", x by LDS-DMA, swapped-operand 16-byte write-through stores) where it measured faster than v3 on MI355X
+// (tools/sk4_sweep.py, profiles/r02_*): 64 < M <= 128 -> 128-row blocks for wide N, 64-row blocks for N < 4096;
+// 32 < M <= 64 -> one 64-row block; M <= 16 -> one 16-row block.  EPI 4: slab, 3: SwiGLU.
+// pg_tune->stream_gemm bits: 1 wide-N slabs (qkv, gen_head, lm_head), 2 narrow-N slabs (o, down), 4 SwiGLU gate|up,
+// 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue instead of the direct one.
+template <int EPI>
+static bool sk4_prod(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+    // -1 (default): what measured faster IN the decode loop on MI355X (tools/ab_loop.sh, profiles/r02_b_sk4_ab.md): every class at
+    // M <= 64 (48 KiB blocks, 2-3 per CU: loop -3.3 % at bs=32, -6.2 % at bs=8), only the narrow-N slabs at M = 128 (-1.5 %;
+    // the 128-row blocks own 96 KiB of LDS = one block per CU and lose 0.7-2.6 % in the loop although they win the microbenchmark)
+    const int sg = pg_tune->stream_gemm >= 0 ? pg_tune->stream_gemm : (M > 64 ? 2 : 15);
+    if (!sg || !Wt || M > 128) return false;
+    constexpr bool SW = EPI == 3;
+    const bool wide = N >= 4096;
+    if (SW ? !(sg & 4) : !(sg & (wide ? 1 : 2))) return false;
+    if (M > 64) {
+        if constexpr (SW) {
+            if (sg & 16) return sk4_nck<8, 3, 3, 1, 1>(s, x, Wt, out, M, N, K, S);
+            return sk4_nck<8, 3, 3, 3, 1>(s, x, Wt, out, M, N, K, S);
+        } else {
+            if (wide) return sk4_nck<8, 3, 3, EPI, 1>(s, x, Wt, out, M, N, K, S);
+            return sk4_nck<4, 3, 3, EPI, 2>(s, x, Wt, out, M, N, K, S);
+        }
+    }
+    if (M > 32) {
+        if constexpr (SW) { if (sg & 16) return sk4_nck<4, 3, 3, 1, 2>(s, x, Wt, out, M, N, K, S); }
+        return sk4_nck<4, 3, 3, EPI, 2>(s, x, Wt, out, M, N, K, S);
+    }
+    if (M <= 16 && (sg & 8)) {
+        if constexpr (SW) { if (sg & 16) return sk4_nck<1, 4, 3, 1, 4>(s, x, Wt, out, M, N, K, S); }
+        return sk4_nck<1, 4, 3, EPI, 4>(s, x, Wt, out, M, N, K, S);
+    }
+    return false;
+}
 void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, const bf16* Wt) {
     if (M <= 0) return;
+    if (sk4_prod<4>(s, x, Wt, out, M, N, K, S)) return;
     if (Wt && sk3_prod_tiled<0, true>(s, x, Wt, out, M, N, K, S)) return;
     if (!sk3_prod<0>(s, x, W, out, M, N, K, S)) launch_gemm_skinny_v1(s, x, W, out, M, N, K, S);
 }
@@ -601,6 +933,7 @@ void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out,
 // shape has no fused instantiation (caller falls back to slabs + silu_mul kernel).
 bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K, const bf16* Wt) {
     if (M <= 0) return true;
+    if (sk4_prod<3>(s, x, Wt, (float*)h, M, N, K, 1)) return true;
     if (Wt && sk3_prod_tiled<1, true>(s, x, Wt, (float*)h, M, N, K, 1)) return true;
     return sk3_prod<1>(s, x, W, (float*)h, M, N, K, 1);
 }
