@@ -343,7 +343,32 @@ def golden_full_width(T=48):
     print("full-width sample_image ok; oracle-vs-transformers logits err", err)
 
 
+def golden_text():
+    """The chat template through the REFERENCE's own conversation.py (imported by file path): sft prompts for a set
+    of (caption, grounding, stage) cases -> tests/golden/text_golden.json; asserts the oracle restatement equals it."""
+    import json
+    conv_mod = _load("ref_conversation", "/root/reference/three_party/Janus/janus/utils/conversation.py")
+    cases = [("a yellow car in front of the tree", "<grounding><ref>a yellow car</ref><box>[120,400,530,880]</box></grounding>", False),
+             ("  two dogs playing \n", "", False), ("a cat", "<grounding>", True), ("x", None, False),
+             ("a kitchen with a table", "<grounding><ref>table</ref><box>[0,500,1000,1000]</box><ref>lamp</ref><box>[400,0,600,300]</box></grounding>", False)]
+    out = []
+    for caption, grounding, stage1 in cases:
+        conv = conv_mod.get_conv_template("deepseek")
+        conv.set_system_message("")
+        for role, content in (("<|User|>", caption), ("<|Assistant|>", f"{grounding}")):
+            conv.append_message(role, content.strip())
+        sft = conv.get_prompt().strip()                                # processing_vlm.py:171-177
+        prompt = sft if stage1 else sft + "<begin_of_image>"            # plangen_base.py:252-255
+        assert R.wrap_uni_prompt_text(caption, grounding, stage1) == prompt, (caption, grounding)
+        out.append(dict(caption=caption, grounding=grounding, in_stage1=stage1, prompt=prompt))
+    json.dump(out, open(os.path.join(OUT, "text_golden.json"), "w"), ensure_ascii=False, indent=1)
+    print("text template ok:", len(out), "cases")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "text":
+        golden_text()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fullwidth":
         golden_full_width()
         return
@@ -354,6 +379,7 @@ def main():
     golden_llama_and_sampling()
     golden_vq_full()
     golden_full_width()
+    golden_text()
 
 
 if __name__ == "__main__":

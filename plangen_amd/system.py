@@ -3,8 +3,10 @@
 ``pad_input_ids`` (:699-725), ``t2i_infer_collate_batch`` (:636-697), ``t2i`` (:525-565),
 ``sample_image`` (:567-607) and ``x2t`` (:513-523), running on the MI355X engine.
 
-The tokenizer (HF LlamaTokenizerFast files) is not part of the path, so prompts enter as
-token-id lists -- what ``wrap_uni_prompt`` returns (:232-261).
+Prompts enter as token-id lists -- what ``wrap_uni_prompt`` returns (:232-261); with a tokenizer plugged in
+(``System(codec=...)``, plangen_amd/textproc.py) the text steps either side of the path run too: the chat template,
+``decode_plan_text_batch`` / ``decode_mmu_text_batch`` (:296-325), the stage-1 -> stage-2 re-prompt (:380-390) and
+``trans_gr_to_creati`` (:460-473).
 """
 from __future__ import annotations
 
@@ -72,13 +74,15 @@ class System:
     temperature, use_teacher_forcing, debug_max_seq_len, janus_hw.
     """
 
-    def __init__(self, cfg: PlanGenConfig, engine: Engine, args: Optional[SimpleNamespace] = None):
+    def __init__(self, cfg: PlanGenConfig, engine: Engine, args: Optional[SimpleNamespace] = None, codec=None):
         self.cfg = cfg
         self.engine = engine
+        self.codec = codec                # tokenizer (plangen_amd.textproc.HFCodec / TagWordCodec); None: ids only
+        self.last_generated_tokens = None
         self.vl_gpt = MultiModalityCausalLM(engine)
         self.args = args or SimpleNamespace(seed=cfg.seed, parallel_size=1, cfg_weight=cfg.cfg_weight,
                                             temperature=cfg.temperature, use_teacher_forcing=False,
-                                            debug_max_seq_len=None, janus_hw=cfg.img_size)
+                                            debug_max_seq_len=None, janus_hw=cfg.img_size, neg_prompt="")
         self.image_token_num_per_image = cfg.img_tokens
         self.device = engine.device
 
@@ -134,9 +138,10 @@ class System:
     def t2i(self, tokens: torch.Tensor, mask: torch.Tensor, cfg_weight: Optional[float] = None,
             temperature: Optional[float] = None, gt_image: Optional[torch.Tensor] = None,
             edit_region: Optional[torch.Tensor] = None, parallel_size: Optional[int] = None):
-        """System.t2i: (teacher forcing: VQ-encode the ground truth :528-532) -> replicate x
-        parallel_size (:547) -> sample_image -> decode_code (:555).  Returns (dec [B*p,3,S,S]
-        fp32, generated_tokens int32 [B*p, T])."""
+        """System.t2i (plangen_base.py:525-565): (teacher forcing: VQ-encode the ground truth :528-532) -> replicate x
+        parallel_size (:547) -> sample_image -> decode_code (:555).  Returns ``(dec, mask_image)`` like the reference:
+        dec [B*p,3,S,S] fp32; mask_image = the edit region resized to janus_hw (:557-560) under use_teacher_forcing,
+        else None.  The generated tokens stay in ``self.last_generated_tokens`` (int32 [B*p, T])."""
         a = self.args
         cfg_weight = a.cfg_weight if cfg_weight is None else cfg_weight
         temperature = a.temperature if temperature is None else temperature
@@ -144,7 +149,9 @@ class System:
         gt_labels = None
         if a.use_teacher_forcing and gt_image is not None:
             bs = gt_image.shape[0]
-            gt_labels = self.vl_gpt.gen_vision_model.encode(gt_image)[-1][-1].reshape(bs, -1).to(torch.int32)
+            # the reference encodes gt_image.bfloat16() (:530): in bf16 mode the encoder sees bf16 pixels
+            gi = gt_image.to(torch.bfloat16) if self.engine.dtype == "bf16" else gt_image
+            gt_labels = self.vl_gpt.gen_vision_model.encode(gi)[-1][-1].reshape(bs, -1).to(torch.int32)
         if p > 1:
             tokens = torch.cat([tokens] * p)
             mask = torch.cat([mask] * p)
@@ -156,50 +163,121 @@ class System:
         num_gen = tokens.shape[0] // 2
         dec = self.vl_gpt.gen_vision_model.decode_code(toks.to(dtype=torch.int),
                                                        shape=[num_gen, self.cfg.img_dim, self.cfg.grid, self.cfg.grid])
-        return dec, toks
+        self.last_generated_tokens = toks
+        mask_image = None
+        if a.use_teacher_forcing and edit_region is not None:
+            er = edit_region.to(dec.device)
+            bs = er.shape[0]
+            g = self.cfg.grid
+            # resize_pt = torchvision Resize (bilinear, antialias) of the [bs,3,g,g] map to janus_hw (funcs.py:523-528); the
+            # edit map is piecewise constant on the g x g grid and janus_hw is a multiple of g: bilinear without antialias here
+            mask_image = torch.nn.functional.interpolate(er.reshape(bs, 1, g, g).repeat(1, 3, 1, 1).float(), size=(a.janus_hw, a.janus_hw),
+                                                         mode="bilinear", align_corners=False).to(dec)
+        return dec, mask_image
+
+    # -------------------------------------------------------------- a12: text either side of the path
+    def wrap_uni_prompt(self, caption: str, grounding: Optional[str] = None, in_stage1: bool = False):
+        """plangen_base.py:232-261 -> (prompt string, ids LongTensor)."""
+        from .textproc import wrap_uni_prompt_ids
+        prompt, ids = wrap_uni_prompt_ids(self._codec(), caption, grounding, in_stage1)
+        return prompt, torch.as_tensor(ids, dtype=torch.long)
+
+    def _codec(self):
+        if self.codec is None:
+            raise PlanGenError("this step needs a tokenizer: pass codec=HFCodec(janus_path) (or TagWordCodec for offline runs) to System")
+        return self.codec
+
+    def decode_text(self, inputs_ids) -> str:
+        return self._codec().decode([int(t) for t in inputs_ids])
+
+    def decode_plan_text_batch(self, inputs_ids) -> List[str]:
+        from .textproc import cut_plan_text
+        return [cut_plan_text(self.decode_text(t)) for t in inputs_ids]
+
+    def decode_mmu_text_batch(self, inputs_ids) -> List[str]:
+        from .textproc import cut_at_eos
+        eos = self._codec().eos_token_id
+        return [self.decode_text(cut_at_eos([int(v) for v in t], eos)) for t in inputs_ids]
+
+    @staticmethod
+    def trans_gr_to_creati(prompt: str):
+        from .textproc import trans_gr_to_creati
+        return trans_gr_to_creati(prompt)
 
     @torch.no_grad()
-    def uni_generate(self, batch: dict, pred_layout: bool = False, is_mmu: bool = False, pred_image: bool = True,
-                     layout_to_prompt=None, max_new_tokens: int = 512, min_new_tokens: int = 0) -> dict:
-        """System.uni_generate (plangen_base.py:327-458) without the visualisation tail.
+    def uni_generate(self, batch: dict, gen_path: Optional[str] = None, batch_idx=None, pred_layout: bool = True,
+                     pred_image: bool = True, save_local: bool = False, use_uni_prompt_in_t2i: bool = True, is_mmu: bool = False,
+                     layout_to_prompt=None, max_new_tokens: int = 512, min_new_tokens: int = 0, **kwargs) -> dict:
+        """System.uni_generate (plangen_base.py:327-458) without the box-drawing tail (PIL visualisation is outside the path).
 
         task_type 'uni'        : pred_layout=False -> t2i on batch['uni_inputs_ids'/'uni_attention_mask'].
-        task_type 'uni_2stage' : pred_layout=True  -> stage 1 greedy layout tokens from
-            batch['uni_stage1_inputs_ids'/'uni_stage1_attention_mask'] (x2t, :371-377), then
-            ``layout_to_prompt(sample_index, new_token_ids) -> list[int]`` rebuilds the stage-2 prompt ids
-            (the reference does this through the tokenizer on the host: decode_plan_text_batch +
-            wrap_uni_prompt, :296-306,:380-390), then t2i.
-        task_type 'mmu'        : is_mmu=True, pred_image=False -> prepare_inputs_embeds(**batch[
-            'prepare_inputs_infer']) (:365-366) + greedy text decode.
-        Negative prompt ids: batch['neg_inputs_ids'] (one shared list, or one per sample).
-        Returns dict(pr_tokens=..., pr_image=..., pr_layout_ids=..., pr_text_ids=...)."""
+        task_type 'uni_2stage' : stage 1 greedy layout tokens from batch['uni_stage1_inputs_ids'/'uni_stage1_attention_mask']
+            (x2t, :371-377) -> decode_plan_text_batch (:382) -> wrap_uni_prompt(base_caption, layout) per sample
+            (:385-388) -> pad_input_ids (:389) -> t2i.  ``layout_to_prompt(i, new_ids) -> list[int]`` replaces the tokenizer
+            round trip when the caller wants to stay on ids.
+        task_type 'mmu'        : is_mmu, pred_image=False -> prepare_inputs_embeds(**batch['prepare_inputs_infer']) (:365-366)
+            + greedy decode + decode_mmu_text_batch (:379-380).
+        task_type 'plan'       : pred_image=False: layout text only.
+        Negative prompt: batch['neg_inputs_ids'] (ids of wrap_uni_prompt(neg_prompt, ''), :673-686; or one list per sample for
+        use_neg_box, :652-670); when absent it is built from args.neg_prompt through the codec.
+        Returns dict(pr_grounding, pr_image) like the reference (+ pr_layout_ids / pr_text_ids / pr_tokens)."""
         out = {}
         dev = self.device
-        if is_mmu:
-            emb = self.vl_gpt.prepare_inputs_embeds(**batch["prepare_inputs_infer"])
-            out["pr_text_ids"] = self.x2t(emb, batch["prepare_inputs_infer"]["attention_mask"].to(dev),
-                                          max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens)
-            if not pred_image:
-                return out
+        base_caption = batch.get("base_caption")
+        pr_grounding = batch.get("gt_grounding")
         if pred_layout:
-            ids1 = batch["uni_stage1_inputs_ids"].to(dev)
-            emb1 = self.vl_gpt.language_model.get_input_embeddings()(ids1)
-            layout = self.x2t(emb1, batch["uni_stage1_attention_mask"].to(dev), max_new_tokens=max_new_tokens,
-                              min_new_tokens=min_new_tokens)
-            out["pr_layout_ids"] = layout
-            if layout_to_prompt is None:
-                raise PlanGenError("uni_2stage needs layout_to_prompt (tokenizer round trip of the predicted layout)")
-            rows = layout.cpu().tolist()
-            cond = [list(layout_to_prompt(i, r)) for i, r in enumerate(rows)]
-        else:
+            if is_mmu:
+                pin = batch["prepare_inputs_infer"]
+                emb = self.vl_gpt.prepare_inputs_embeds(**{k: v for k, v in pin.items() if k != "attention_mask"})
+                attention_mask = pin["attention_mask"]
+            else:
+                ids1 = batch["uni_stage1_inputs_ids"].to(dev)
+                attention_mask = batch["uni_stage1_attention_mask"]
+                emb = self.vl_gpt.language_model.get_input_embeddings()(ids1)
+            outputs = self.x2t(emb, attention_mask.to(dev), max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens)
+            out["pr_text_ids" if is_mmu else "pr_layout_ids"] = outputs
+            rows = outputs.cpu().tolist()
+            if self.codec is not None:
+                pr_grounding = self.decode_mmu_text_batch(rows) if is_mmu else self.decode_plan_text_batch(rows)
+            else:
+                pr_grounding = None
+            if pred_image:
+                if layout_to_prompt is not None:
+                    all_ids = [list(layout_to_prompt(i, r)) for i, r in enumerate(rows)]
+                elif pr_grounding is not None and base_caption is not None:
+                    all_ids = [self.wrap_uni_prompt(c, g)[1].tolist() for c, g in zip(base_caption, pr_grounding)]
+                else:
+                    raise PlanGenError("uni_2stage needs a tokenizer (System(codec=...)) with batch['base_caption'], or layout_to_prompt")
+                uni_ids, uni_mask = self.pad_input_ids(all_ids)
+                bs = len(all_ids)
+                batch = dict(batch, uni_inputs_ids=uni_ids,
+                             uni_attention_mask=torch.cat([uni_mask, torch.ones((bs, self.image_token_num_per_image), dtype=uni_mask.dtype)], -1))
+        if pred_image:
+            if not use_uni_prompt_in_t2i:
+                raise PlanGenError("use_uni_prompt_in_t2i=False: the reference asserts False on this branch too (plangen_base.py:645-648)")
             ids, mask = batch["uni_inputs_ids"], batch["uni_attention_mask"]
             L = ids.shape[1]
             m = mask[:, :L]
             cond = [ids[i][m[i].bool()].tolist() for i in range(ids.shape[0])]
-        cfg_ids, cfg_mask = self.t2i_infer_collate_batch(cond, batch["neg_inputs_ids"])
-        dec, toks = self.t2i(cfg_ids, cfg_mask, gt_image=batch.get("image"), edit_region=batch.get("edit_region"))
-        out["pr_tokens"] = toks
-        out["pr_image"] = dec.float()
+            neg = batch.get("neg_inputs_ids")
+            if neg is None:
+                neg = self.wrap_uni_prompt(getattr(self.args, "neg_prompt", ""), "")[1].tolist()
+            cfg_ids, cfg_mask = self.t2i_infer_collate_batch(cond, neg)
+            dec, edit_mask = self.t2i(cfg_ids, cfg_mask, gt_image=batch.get("image"), edit_region=batch.get("edit_region"))
+            out["pr_tokens"] = self.last_generated_tokens
+            out["pr_image"] = dec.float()
+            out["edit_mask"] = edit_mask
+        else:
+            out["pr_image"] = batch.get("image")
+        out["pr_grounding"] = pr_grounding
+        if save_local and gen_path is not None:
+            # the reference's per-batch layout record (:416-420); its annotated PNG grid is box drawing, not part of the path
+            import json
+            import os
+            os.makedirs(gen_path, exist_ok=True)
+            with open(os.path.join(gen_path, f"{batch_idx}_layout.json"), "w") as f:
+                json.dump(dict(base_caption=base_caption, gt_grounding=batch.get("gt_grounding"),
+                               pr_grounding=pr_grounding if pred_layout else ""), f)
         return out
 
     @torch.no_grad()

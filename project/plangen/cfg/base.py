@@ -12,13 +12,17 @@ cfg_weight = 5.0                       # base.py:162
 temperature = 1.0
 use_teacher_forcing = False            # base.py:36
 use_neg_box = False                    # base.py:121
-neg_prompt_ids = None                  # tokenised negative prompt (base.py:129 holds the string)
+neg_prompt = ""                        # base.py:129: wrapped as wrap_uni_prompt(neg_prompt, '') for every uncond CFG row (:673)
+neg_prompt_ids = None                  # optional pre-tokenised negative prompt (no tokenizer files needed)
+max_new_tokens = 512                   # x2t (:513-523)
+test_start = 0                         # base.py: skip batches before this index (:1135)
+synthetic = False                      # True: seeded random-init weights + offline tokenizer (plumbing runs only)
 max_test_len = 8                       # base.py:34: number of test batches
 debug_max_seq_len = None               # base.py:135
 dtype = "bf16"
 test_batch_size = 8
 test_data = dict(
-    data_name="synthetic",             # 'synthetic' or a JSONL file of pre-tokenised prompts
-    task_type="uni",                   # 'uni' | 'uni_2stage' | 'mmu'
-    ids_file=None,
+    data_name="synthetic",             # 'synthetic' or the dataset tag used in the output path
+    task_type="uni",                   # 't2i' | 'uni_2stage' | 'uni' | 'mmu' | 'plan'   (plangen_base.py:1112-1127)
+    data_file=None,                    # JSONL: text rows (base_caption / gt_grounding / image_id) or pre-tokenised rows
 )

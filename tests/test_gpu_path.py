@@ -173,7 +173,9 @@ def test_t2i_end_to_end_f32(tiny_cfg, tiny_weights):
     g, ids, mask = _golden()
     e = get_engine(tiny_cfg, tiny_weights, "f32")
     sysm = System(tiny_cfg, e)
-    dec, toks = sysm.t2i(ids, mask, cfg_weight=5.0, temperature=0.0)
+    dec, mask_image = sysm.t2i(ids, mask, cfg_weight=5.0, temperature=0.0)
+    toks = sysm.last_generated_tokens
+    assert mask_image is None                                   # no teacher forcing (plangen_base.py:561-562)
     assert np.array_equal(toks.cpu().numpy(), g["tokens"])
     assert ((dec.cpu() - torch.from_numpy(g["image"])) ** 2).mean().item() <= PIXEL_MSE
 

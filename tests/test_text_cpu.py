@@ -1,0 +1,91 @@
+"""CPU: the text plumbing either side of the hot path: chat template vs the fixture generated
+by the reference's own conversation.py, the layout / answer post-processing rules vs the oracle restatement
+(plangen_base.py:296-325, :460-473), the offline codec, and the CLI driver's error behaviour."""
+import json
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import ref_cpu as R
+from plangen_amd import textproc as T
+
+
+def test_chat_template_matches_reference_conversation_py():
+    cases = json.load(open(os.path.join(GOLDEN, "text_golden.json")))
+    assert len(cases) >= 5
+    for c in cases:
+        assert T.wrap_uni_prompt_text(c["caption"], c["grounding"], c["in_stage1"]) == c["prompt"], c
+    assert T.wrap_t2i_prompt_text("two dogs playing") == "<|User|>: two dogs playing\n\n<|Assistant|>:<begin_of_image>"
+
+
+@pytest.mark.parametrize("text", [
+    "<ref>a cat</ref><box>[12,40,500,620]</box></grounding> trailing <ref>x</ref>",
+    "</grounding></grounding>", "no closing tag at all", "", "<ref>a</ref><box>[1,2,3,4]</box><ref>b c</ref><box>[10,20,30,40]</box></grounding>",
+])
+def test_plan_text_rules_match_oracle(text):
+    assert T.cut_plan_text(text) == R.decode_plan_text(text)
+    full = T.cut_plan_text(text)
+    assert T.trans_gr_to_creati(full) == R.trans_gr_to_creati(full)
+    assert T.get_pr_grounding_part("junk " + full).startswith("<grounding>")
+
+
+def test_box_regex_values():
+    boxes, names = T.trans_gr_to_creati("<grounding><ref>a red car</ref><box>[120,400,530,880]</box><ref>tree</ref><box>[0,0,1000,1000]</box></grounding>")
+    assert names == ["a red car", "tree"] and boxes == [[0.12, 0.4, 0.53, 0.88], [0.0, 0.0, 1.0, 1.0]]
+    assert T.trans_gr_to_creati("<grounding></grounding>") == ([], [])
+    with pytest.raises(ValueError):
+        T.trans_gr_to_creati("<ref>a</ref><box>[1,2,3]</box>")          # the reference's map(int, ...) unpack fails the same way
+
+
+def test_cut_at_eos_matches_oracle():
+    for ids in ([5, 9, 7, 4, 7], [7], [1, 2, 3], []):
+        assert T.cut_at_eos(ids, 7) == R.cut_mmu_ids(ids, 7)
+
+
+def test_tagword_codec_round_trip_and_stage1_drop():
+    c = T.TagWordCodec(512)
+    gr = "<grounding><ref>a small red cat</ref><box>[12,40,500,620]</box></grounding>"
+    prompt, ids = T.wrap_uni_prompt_ids(c, "a cat on the table", gr)
+    assert c.decode(ids) == prompt and ids[0] == c.bos_token_id and max(ids) < 512
+    p1, ids1 = T.wrap_uni_prompt_ids(c, "a cat on the table", "<grounding>", in_stage1=True)
+    assert p1.endswith("<grounding><｜end▁of▁sentence｜>") and c.decode(ids1).endswith("<grounding>")      # last token (EOS tag) dropped
+    # ids of a layout survive decode -> cut -> parse
+    layout_ids = c.encode("<ref>a dog</ref><box>[1,2,3,4]</box></grounding> and more")[1:]
+    text = T.cut_plan_text(c.decode(layout_ids))
+    assert T.trans_gr_to_creati(text) == ([[0.001, 0.002, 0.003, 0.004]], ["a dog"])
+    with pytest.raises(ValueError):
+        small = T.TagWordCodec(40)
+        small.encode("many different words exceed this tiny vocabulary quickly indeed")
+
+
+def _cli(**over):
+    import train
+    from conftest import ROOT
+    opts = ["test=True", "tiny=True", "test_batch_size=2", "max_test_len=1"] + [f"{k}={v!r}" for k, v in over.items()]
+    return train.parse_args(["--cfg", os.path.join(ROOT, "project/plangen/cfg/uni/h_text_ump+oimsam.py"), "--opt", *opts])
+
+
+def test_cli_rejects_unknown_task_before_touching_the_gpu():
+    from plangen_amd.engine import PlanGenError
+    from project.plangen.plangen_base import System
+    a = _cli()
+    a.test_data = dict(a.test_data, task_type="segmentation")
+    with pytest.raises(PlanGenError, match="task_type"):
+        System(a, None)
+
+
+def test_cli_resume_errors_are_loud(tmp_path):
+    """a missing explicit resume path / a missing janus_path must not fall back to random weights."""
+    from project.plangen.plangen_base import System
+    s = object.__new__(System)
+    s.engine = None
+    s.synthetic = False
+    s.cli = SimpleNamespace(out_path=str(tmp_path), resume=str(tmp_path / "checkpoint-9"), janus_path=str(tmp_path / "nope"))
+    with pytest.raises(FileNotFoundError, match="resume"):
+        s.resume()
+    s.cli.resume = None
+    with pytest.raises(FileNotFoundError, match="janus_path"):
+        s.resume()
