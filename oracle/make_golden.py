@@ -343,6 +343,52 @@ def golden_full_width(T=48):
     print("full-width sample_image ok; oracle-vs-transformers logits err", err)
 
 
+@torch.no_grad()
+def golden_siglip_crosscheck():
+    """a13 / f2: timm is not installed, so the reference's own ``VisionTransformer`` class (siglip_vit.py) cannot be
+    instantiated here and the SigLIP row stays PARITY UNPINNED.  What CAN be done: an independent implementation of the
+    same published architecture -- transformers' ``SiglipVisionModel`` (hidden_act='gelu' to match the nn.GELU of
+    siglip_vit.py:337, layer_norm_eps 1e-6 as :336, no pooling head = ignore_head) -- on the same seeded weights.
+    A THIRD-PARTY CROSS-CHECK of oracle.siglip_forward, not a reference golden vector."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    cfg = R.OracleCfg(**TINY)
+    W = R.make_weights(cfg, seed=1, with_encoder=True, with_vision=True)
+    hc = SiglipVisionConfig(hidden_size=cfg.vit_width, intermediate_size=cfg.vit_mlp, num_hidden_layers=cfg.vit_layers,
+                            num_attention_heads=cfg.vit_heads, num_channels=3, image_size=cfg.vit_img, patch_size=cfg.vit_patch,
+                            hidden_act="gelu", layer_norm_eps=1e-6, attention_dropout=0.0, vision_use_head=False)
+    m = SiglipVisionModel(hc).eval()
+    VT = "vision_model.vision_tower."
+    sd = {"vision_model.embeddings.patch_embedding.weight": W[VT + "patch_embed.proj.weight"],
+          "vision_model.embeddings.patch_embedding.bias": W[VT + "patch_embed.proj.bias"],
+          "vision_model.embeddings.position_embedding.weight": W[VT + "pos_embed"][0],
+          "vision_model.post_layernorm.weight": W[VT + "norm.weight"], "vision_model.post_layernorm.bias": W[VT + "norm.bias"]}
+    Cw = cfg.vit_width
+    for i in range(cfg.vit_layers):
+        b, h = f"{VT}blocks.{i}.", f"vision_model.encoder.layers.{i}."
+        qkv_w, qkv_b = W[b + "attn.qkv.weight"], W[b + "attn.qkv.bias"]
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):          # timm packs q|k|v rows (siglip_vit.py:164-176)
+            sd[h + f"self_attn.{nm}.weight"] = qkv_w[j * Cw:(j + 1) * Cw]
+            sd[h + f"self_attn.{nm}.bias"] = qkv_b[j * Cw:(j + 1) * Cw]
+        sd[h + "self_attn.out_proj.weight"], sd[h + "self_attn.out_proj.bias"] = W[b + "attn.proj.weight"], W[b + "attn.proj.bias"]
+        for a_, b_ in (("layer_norm1", "norm1"), ("layer_norm2", "norm2")):
+            sd[h + a_ + ".weight"], sd[h + a_ + ".bias"] = W[b + b_ + ".weight"], W[b + b_ + ".bias"]
+        for a_ in ("fc1", "fc2"):
+            sd[h + f"mlp.{a_}.weight"], sd[h + f"mlp.{a_}.bias"] = W[b + f"mlp.{a_}.weight"], W[b + f"mlp.{a_}.bias"]
+    if not any(k.startswith("vision_model.") for k in m.state_dict()):          # transformers >= 5: no wrapper prefix
+        sd = {k[len("vision_model."):]: v for k, v in sd.items()}
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all("position_ids" in k for k in missing.missing_keys), missing
+    g = torch.Generator().manual_seed(31)
+    img = torch.rand(3, 3, cfg.vit_img, cfg.vit_img, generator=g) * 2 - 1
+    hf = m(pixel_values=img).last_hidden_state
+    mine = R.siglip_forward(W, cfg, img)
+    err = (hf - mine).abs().max().item()
+    assert err < 2e-5, err
+    np.savez_compressed(os.path.join(OUT, "siglip_tiny_crosscheck.npz"), images=img.numpy(), features=hf.numpy(),
+                        aligned=R.vision_encode(W, cfg, img).numpy(), wsum=wsum(W), source="transformers.SiglipVisionModel (third-party cross-check)")
+    print("siglip cross-check ok; oracle vs transformers.SiglipVisionModel err", err)
+
+
 def golden_text():
     """The chat template through the REFERENCE's own conversation.py (imported by file path): sft prompts for a set
     of (caption, grounding, stage) cases -> tests/golden/text_golden.json; asserts the oracle restatement equals it."""
@@ -369,6 +415,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "text":
         golden_text()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "siglip":
+        golden_siglip_crosscheck()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fullwidth":
         golden_full_width()
         return
@@ -380,6 +429,7 @@ def main():
     golden_vq_full()
     golden_full_width()
     golden_text()
+    golden_siglip_crosscheck()
 
 
 if __name__ == "__main__":

@@ -124,10 +124,11 @@ def test_temperature_limits(tiny_cfg, tiny_weights):
 
 
 def test_cli_validation_writes_images(tmp_path):
-    """python train.py --cfg ... --opt test=True ... -> System.validation (tiny config, synthetic prompts)."""
+    """python train.py --cfg ... --opt test=True ... -> System.validation (tiny config, synthetic prompts, bf16 default);
+    the per-task dispatch and the output tree are covered in tests/test_gpu_cli.py."""
     import train
     out = train.parse_args(["--cfg", "project/plangen/cfg/uni/h_text_ump+oimsam.py", "--opt", "test=True", "tiny=True",
-                            "resume=None", f"out_path='{tmp_path}'", "test_batch_size=2", "max_test_len=2", "max_prompt=64",
+                            "resume=None", f"out_path='{tmp_path}'", "test_batch_size=2", "max_test_len=2", "max_prompt=200",
                             "janus_path=None"])
     import importlib
     System = importlib.import_module(out.system_cls_path).System
@@ -135,9 +136,10 @@ def test_cli_validation_writes_images(tmp_path):
     m.setup_data(None)
     m.resume(None)
     res = m.validation(0)
-    assert res["images"] == 4
-    files = os.listdir(res["out_dir"])
-    assert sum(f.endswith((".png", ".pt")) for f in files) == 4 and sum(f.endswith("_tokens.json") for f in files) == 2
+    assert res["images"] == 4 and res["task_type"] == "uni"
+    files = os.listdir(os.path.join(res["out_dir"], "pr_image"))
+    assert sorted(files) == ["0.png", "1.png", "2.png", "3.png"]
+    m.engine.close()
 
 
 def test_decode_graph_survives_fresh_buffers_seeds_and_temperatures(tiny_cfg, tiny_weights, ocfg):
