@@ -233,3 +233,19 @@ def test_rmsnorm_wide_rows(tiny_cfg, tiny_weights, H, NV):
     ref = w * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))
     assert torch.allclose(xnew.cpu(), xr, atol=1e-5)
     assert (out.float().cpu() - ref).abs().max() < 1e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 2048, 2048), (128, 2048, 5632), (64, 6144, 2048), (64, 2048, 5632), (16, 6144, 2048), (8, 2048, 2048)])
+def test_stream_gemm_is_deterministic_under_repetition(tiny_cfg, tiny_weights, M, N, K):
+    """The v4 decode GEMM (x tile by LDS-DMA, counted vmcnt + raw s_barrier) on the shapes the default dispatch sends to
+    it: 60 launches must give bit-identical slabs (a stale LDS read would differ by a whole 128-wide K chunk) and agree
+    with fp64."""
+    e = _eng(tiny_cfg, tiny_weights, "bf16")
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    a = _round(torch.randn(M, K, generator=g), "bf16")
+    w = _round(torch.randn(N, K, generator=g) * 0.05, "bf16")
+    first = e.op_gemm(a, w, 4)
+    ref = a.double() @ w.double().t()
+    assert (first.cpu().double() - ref).abs().max().item() < 2e-4 * ref.abs().max().item() + 1e-4
+    for _ in range(60):
+        assert torch.equal(e.op_gemm(a, w, 4), first)
