@@ -372,9 +372,13 @@ def run_rank(args):
 
 
 def kernel_src_sha():
-    """Identity of the decode-attention kernel source a PMC ratio belongs to (stale ratios are dropped)."""
+    """Identity of the decode-attention kernel SOURCE a PMC ratio belongs to (hash of the kernel's text in llm_kernels.hip,
+    from its signature to its launcher): a ratio measured on another version of the kernel is not applied."""
     import hashlib
-    return hashlib.sha256(open(os.path.join(ROOT, "plangen_amd", "csrc", "llm_kernels.hip"), "rb").read()).hexdigest()[:16]
+    src = open(os.path.join(ROOT, "plangen_amd", "csrc", "llm_kernels.hip")).read()
+    a = src.find("void attn_decode_fused_kernel(")
+    b = src.find("void launch_attn_decode_fused(")
+    return hashlib.sha256(src[a:b].encode()).hexdigest()[:16]
 
 
 def main(argv=None):

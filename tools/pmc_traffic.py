@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=256)
     ap.add_argument("--tokens", type=int, default=24)
     ap.add_argument("--kernel", default="attn_decode_fused_kernel")
+    ap.add_argument("--json", default=None, help="write the ratio + provenance (kernel symbol, source hash, commit, command) here")
+    ap.add_argument("--cmd", default="")
     a = ap.parse_args()
     from bench import synth_prompts
     ids, mask = synth_prompts(a.batch, a.prompt_len, 102400, 100002, 0)
@@ -50,6 +52,22 @@ def main():
     print(f"FETCH_SIZE x2 (gfx950 correction)      : {2 * f_kb * 1024 / 1e6:9.2f} MB   ratio to algorithmic {2 * f_kb * 1024 / algo:.3f}")
     print(f"WRITE_SIZE raw per launch (uncalibrated): {w_kb * 1024 / 1e6:9.2f} MB")
     print(f"traffic (2*FETCH + WRITE)              : {(2 * f_kb + w_kb) * 1024 / 1e6:9.2f} MB")
+    if a.json:
+        import json
+        import subprocess
+        from bench import kernel_src_sha
+        con = sqlite3.connect(a.fetch_db)
+        sym = con.execute("select name from pmc_events where name like ? limit 1", (f"%{a.kernel}%",)).fetchone()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            commit = ""
+        json.dump({"kernel": a.kernel, "kernel_symbol": sym[0] if sym else a.kernel, "kernel_src_sha": kernel_src_sha(), "commit": commit,
+                   "traffic_per_algorithmic_byte": (2 * f_kb + w_kb) * 1024 / algo, "algorithmic_mb_per_launch": algo / 1e6,
+                   "fetch_x2_mb": 2 * f_kb * 1024 / 1e6, "write_mb": w_kb * 1024 / 1e6, "launches": nf, "command": a.cmd,
+                   "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE uncalibrated"},
+                  open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
