@@ -832,32 +832,12 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 50: return sk3_prod_nck<8, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W layout
         case 51: return sk3_prod_nck<4, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W, 64-row M blocks
         // v4 (x by LDS-DMA): MT / x ring depth / W ring depth / min blocks per CU
-        case 70: return sk4_nck<4, 3, 2, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 71: return sk4_nck<4, 3, 3, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 72: return sk4_nck<4, 4, 3, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 73: return sk4_nck<4, 4, 4, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 74: return sk4_nck<8, 3, 3, 0, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 75: return sk4_nck<8, 4, 4, 0, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 76: return sk4_nck<4, 3, 3, 0, 3>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 77: return sk4_nck<2, 4, 3, 0, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        // ablations of v71 (MT 4, XD 3, WD 3) and v74 (MT 8): 1 no x, 2 no MFMA, 4 no stores
-        case 91: return sk4_nck<4, 3, 3, 0, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 92: return sk4_nck<4, 3, 3, 0, 2, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 93: return sk4_nck<4, 3, 3, 0, 2, 3>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 94: return sk4_nck<4, 3, 3, 0, 2, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 97: return sk4_nck<4, 3, 3, 0, 2, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 95: return sk4_nck<4, 3, 3, 0, 2, 5>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 96: return sk4_nck<4, 3, 3, 0, 2, 6>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 107: return sk4_nck<8, 3, 3, 0, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 170: return sk4_nck<2, 4, 3, 4, 4, 8>(s, x, W, out, M, N, K, S) ? 128 : 0;     // v160 with vmcnt(0) before every barrier
         case 160: return sk4_nck<2, 4, 3, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 32-row blocks
         case 161: return sk4_nck<1, 4, 3, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 16-row blocks
-        case 162: return sk4_nck<1, 4, 4, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 163: return sk4_nck<2, 4, 4, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 164: return sk4_nck<4, 4, 4, 4, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 150: return sk4_nck<8, 3, 3, 4, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;        // v123 with write-through stores
         case 151: return sk4_nck<4, 3, 3, 4, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 64-row blocks, write-through stores
-        case 152: return sk4_nck<4, 3, 3, 2, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 64-row blocks, direct nt stores
         // ablations of v123 (MT 8, XD 3, WD 3, direct stores)
         case 141: return sk4_nck<8, 3, 3, 2, 1, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // no x
         case 142: return sk4_nck<8, 3, 3, 2, 1, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;     // no MFMA
@@ -868,23 +848,9 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 147: return sk4_nck<8, 3, 3, 2, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;     // W only
         // 8 waves per block (two row halves): LDS reads of one wave under the MFMAs of the other
         case 130: return sk4_nck<8, 3, 3, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 131: return sk4_nck<8, 4, 4, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 132: return sk4_nck<8, 3, 2, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 133: return sk4_nck<8, 3, 6, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 134: return sk4_nck<4, 3, 3, 2, 2, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;    // 64-row blocks, 8 waves of 2 m-tiles
-        case 120: return sk4_nck<8, 3, 8, 0, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // deep W ring, transposed stores
         case 121: return sk4_nck<8, 3, 8, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // deep W ring, direct 16-byte stores
-        case 122: return sk4_nck<8, 4, 8, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // + x ring 4
         case 123: return sk4_nck<8, 3, 3, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // shallow W ring, direct stores
-        case 124: return sk4_nck<4, 3, 8, 2, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;     // 64-row blocks, deep W, direct stores
-        case 125: return sk4_nck<4, 4, 6, 2, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 126: return sk4_nck<8, 3, 5, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 108: return sk4_nck<8, 3, 6, 0, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;     // W only, ring 6
-        case 109: return sk4_nck<8, 3, 8, 0, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;     // W only, ring 8
-        case 110: return sk4_nck<8, 3, 2, 0, 1, 7>(s, x, W, out, M, N, K, S) ? 128 : 0;     // W only, ring 2
-        case 104: return sk4_nck<8, 3, 3, 0, 1, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;
-        case 80: return sk4_nck<4, 3, 3, 1, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;            // SwiGLU epilogue (S = 1)
-        case 81: return sk4_nck<8, 3, 3, 1, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
         default: return 0;
     }
 }
