@@ -322,7 +322,7 @@ def run_rank(args):
             pj = os.path.join(ROOT, "profiles", "pmc_attn.json")
             if os.path.exists(pj):
                 pm = json.load(open(pj))
-                if pm.get("kernel_symbol", "").startswith(kname) and pm.get("kernel_src_sha") == kernel_src_sha():
+                if kname in pm.get("kernel_symbol", "") and pm.get("kernel_src_sha") == kernel_src_sha():
                     traffic = pm["traffic_per_algorithmic_byte"] * ta["attn_bytes_sum"] / ta["attn_launches"]
             out["roofline"] = {"bound": "hbm", "kernel": kname + " (RoPE + KV append + decode attention)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
@@ -330,9 +330,14 @@ def run_rank(args):
                                "algorithmic_bytes_per_launch": ta["attn_bytes_sum"] / ta["attn_launches"],
                                "decode_loop_share": ta["attn_ms_sum"] * args.time_stride / max(ta["decode_ms"], 1e-9),
                                "timed_every_nth_step": args.time_stride}
+            # Event timing of SHORT kernels is pessimistic: an event pair around nothing already costs a few us in this eager pass
+            # ("event_pair_overhead_us"; measured ~4.7 us, about half of it lands inside a timed interval).  "avg_launch_us" is
+            # the raw event interval; the rocprofv3 --kernel-trace averages of the graph-replayed loop are in profiles/.
+            empty = cls.get("empty_event_pair", {"ms_sum": 0.0, "launches": 0})
+            out["roofline"]["event_pair_overhead_us"] = empty["ms_sum"] / empty["launches"] * 1e3 if empty["launches"] else None
             classes = {}
             for name, c in cls.items():
-                if not c["launches"]:
+                if not c["launches"] or name == "empty_event_pair":
                     continue
                 gbs = c["bytes_sum"] / (c["ms_sum"] * 1e-3) / 1e9
                 classes[name] = {"bound": "hbm", "avg_launch_us": c["ms_sum"] / c["launches"] * 1e3,

@@ -179,8 +179,8 @@ typedef struct pg_timing {
 } pg_timing;
 int pg_get_timing(pg_handle h, pg_timing* out);
 /* Per-kernel-class sums of the last instrumented decode loop (pg_set_option("time_attn", 1); call pg_get_timing
- * first: it collects the events).  cls 0..7: decode attention, QKV / O / gate|up(+SwiGLU) / down GEMMs, RMSNorm
- * (+ split-K reduce + residual), gen_head, CFG sampler; *bytes_sum = algorithmic HBM bytes of the timed launches
+ * first: it collects the events).  cls 0..8: decode attention, QKV / O / gate|up(+SwiGLU) / down GEMMs, RMSNorm
+ * (+ split-K reduce + residual), gen_head, CFG sampler, 8: event pairs around nothing (instrumentation overhead); *bytes_sum = algorithmic HBM bytes of the timed launches
  * (weights once per launch; K/V once per launch).  Returns PG_ERR_ARG past the last class. */
 int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum, int* launches, double* bytes_sum);
 /* Tuning / measurement switches (defaults in parentheses), PER HANDLE; none changes results except where noted:
