@@ -243,3 +243,76 @@ def test_prefill_big_tile_kernels_equal_small_tile_kernels():
     for r in range(R):
         assert torch.equal(h1[r, pad[r]:], h0[r, pad[r]:]), r
     del e
+
+
+def test_prompt_sharding_is_invisible_in_the_tokens():
+    """BASELINE configs[3] semantics on one GPU: a global batch generated as ONE batch and as contiguous prompt shards
+    (what `bench.py --gpus N --global-batch G` does per rank, with the sampler's RNG keyed on the global image index through
+    `rng_image_offset`) must produce the same SAMPLED tokens, bit for bit, at Janus-Pro-1B size."""
+    from bench import synth_prompts
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.dist import shard_range
+    from plangen_amd.engine import Engine
+    cfg = PlanGenConfig.janus_pro_1b()
+    G, L, T = 12, 64, 10
+    e = Engine(cfg, dtype="bf16", max_rows=2 * G, max_prompt=L, max_new=16, max_images=1)
+    e.init_synthetic(seed=0)
+    ids, mask = synth_prompts(G, L, cfg.vocab, cfg.pad_id, seed=1)
+    pad = Engine.pad_len_from_mask(mask, L)
+    e.prefill(ids, pad)
+    whole = e.decode_image_tokens(T=T, cfg_weight=5.0, temperature=1.0, seed=77).cpu()
+    for world in (2, 3):
+        parts = []
+        for r in range(world):
+            lo, hi = shard_range(G, world, r)
+            e.set_option("rng_image_offset", lo)
+            e.prefill(ids[2 * lo:2 * hi], pad[2 * lo:2 * hi])
+            parts.append(e.decode_image_tokens(T=T, cfg_weight=5.0, temperature=1.0, seed=77).cpu())
+        e.set_option("rng_image_offset", 0)
+        assert torch.equal(torch.cat(parts), whole), world
+    assert len(torch.unique(whole)) > G                      # really sampled, not a constant
+    e.close()
+
+
+def test_bench_shape_secondary_configs_run_with_assertions():
+    """BASELINE configs[2] (uni_2stage, bs=32) and configs[4] (mmu, bs=64) at their bench batch sizes with shortened decode
+    lengths: shapes, value ranges, determinism across calls, and row invariance (row 0 alone == row 0 in the batch)."""
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    cfg = PlanGenConfig.janus_pro_1b()
+    g = torch.Generator().manual_seed(3)
+    # uni_2stage: 32 stage-1 prompts of 128 tokens -> 12 forced layout tokens; then 32 CFG pairs -> 6 image tokens
+    B = 32
+    e = Engine(cfg, dtype="bf16", max_rows=2 * B, max_prompt=128, max_new=16, max_images=1, with_lm_head=True)
+    e.init_synthetic(seed=0)
+    ids1 = torch.randint(10, cfg.vocab - 2048, (B, 128), generator=g).int()
+    e.prefill(ids1, [0] * B, position_mode=1)
+    txt = e.generate_text_greedy(12, cfg.eos_id, min_new_tokens=12).cpu()
+    e.prefill(ids1, [0] * B, position_mode=1)
+    txt2 = e.generate_text_greedy(12, cfg.eos_id, min_new_tokens=12).cpu()
+    assert txt.shape == (B, 12) and torch.equal(txt, txt2) and ((txt >= 0) & (txt < cfg.vocab)).all() and (txt != cfg.eos_id).all()
+    e.prefill(ids1[:1], [0], position_mode=1)
+    assert torch.equal(e.generate_text_greedy(12, cfg.eos_id, min_new_tokens=12).cpu()[0], txt[0])
+    from bench import synth_prompts
+    ids2, mask2 = synth_prompts(B, 128, cfg.vocab, cfg.pad_id, seed=2)
+    e.prefill(ids2, Engine.pad_len_from_mask(mask2, 128))
+    toks = e.decode_image_tokens(T=6, cfg_weight=5.0, temperature=0.0).cpu()
+    assert toks.shape == (B, 6) and ((toks >= 0) & (toks < cfg.img_vocab)).all()
+    e.close()
+    # mmu: 64 images through SigLIP-L + aligner, 576 + 16 embeddings per row, 8 forced answer tokens
+    B, P = 64, cfg.vit_tokens
+    e = Engine(cfg, dtype="bf16", max_rows=B, max_prompt=P + 16, max_new=8, max_images=1, with_lm_head=True, with_vision=True,
+               max_vision_images=B)
+    e.init_synthetic(seed=0)
+    pix = (torch.rand(B, 3, cfg.vit_img, cfg.vit_img, generator=g) * 2 - 1)
+    feats = e.vision_encode(pix, dtype=torch.bfloat16)
+    assert feats.shape == (B, P, cfg.hidden) and torch.isfinite(feats.float()).all()
+    assert torch.equal(e.vision_encode(pix[:2], dtype=torch.bfloat16), feats[:2])
+    txt_emb = e.embed_tokens(torch.randint(10, cfg.vocab - 2048, (B, 16), generator=g).int()).to(feats.dtype)
+    emb = torch.cat([txt_emb[:, :1], feats, txt_emb[:, 1:]], 1).contiguous()
+    e.prefill_embeds(emb, [0] * B, position_mode=1)
+    out = e.generate_text_greedy(8, cfg.eos_id, min_new_tokens=8).cpu()
+    assert out.shape == (B, 8) and ((out >= 0) & (out < cfg.vocab)).all()
+    e.prefill_embeds(emb[:1].contiguous(), [0], position_mode=1)
+    assert torch.equal(e.generate_text_greedy(8, cfg.eos_id, min_new_tokens=8).cpu()[0], out[0])
+    e.close()
