@@ -857,12 +857,12 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
 
 // v4 ("stream", x by LDS-DMA, swapped-operand 16-byte write-through stores) where it measured faster than v3 on MI355X
 // (tools/sk4_sweep.py, profiles/r02_*): 64 < M <= 128 -> 128-row blocks for wide N, 64-row blocks for N < 4096;
-// 32 < M <= 64 -> one 64-row block; M <= 16 -> one 16-row block.  EPI 4: slab, 3: SwiGLU.
+// 16 < M <= 64 -> one 64-row block; M <= 16 -> one 16-row block.  EPI 4: slab, 3: SwiGLU.
 // pg_tune->stream_gemm bits: 1 wide-N slabs (qkv, gen_head, lm_head), 2 narrow-N slabs (o, down), 4 SwiGLU gate|up,
 // 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue instead of the direct one.
 template <int EPI>
 static bool sk4_prod(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
-    // -1 (default): what measured faster IN the decode loop on MI355X (tools/ab_loop.sh, profiles/r02_b_sk4_ab.md): every class at
+    // -1 (default): what measured faster IN the decode loop on MI355X (tools/ab_loop.sh, profiles/r02_b_decode_gemm_investigation.md): every class at
     // M <= 64 (48 KiB blocks, 2-3 per CU: loop -3.3 % at bs=32, -6.2 % at bs=8), only the narrow-N slabs at M = 128 (-1.5 %;
     // the 128-row blocks own 96 KiB of LDS = one block per CU and lose 0.7-2.6 % in the loop although they win the microbenchmark)
     const int sg = pg_tune->stream_gemm >= 0 ? pg_tune->stream_gemm : (M > 64 ? 2 : 15);
@@ -879,11 +879,11 @@ static bool sk4_prod(hipStream_t s, const bf16* x, const bf16* Wt, float* out, i
             return sk4_nck<4, 3, 3, EPI, 2>(s, x, Wt, out, M, N, K, S);
         }
     }
-    if (M > 32) {
+    if (M > 16) {                               // 17..64 rows: one 64-row block (rows beyond M clamped; bs=16 loop -1.6 %, bs=32 -3.3 %)
         if constexpr (SW) { if (sg & 16) return sk4_nck<4, 3, 3, 1, 2>(s, x, Wt, out, M, N, K, S); }
         return sk4_nck<4, 3, 3, EPI, 2>(s, x, Wt, out, M, N, K, S);
     }
-    if (M <= 16 && (sg & 8)) {
+    if (sg & 8) {
         if constexpr (SW) { if (sg & 16) return sk4_nck<1, 4, 3, 1, 4>(s, x, Wt, out, M, N, K, S); }
         return sk4_nck<1, 4, 3, EPI, 4>(s, x, Wt, out, M, N, K, S);
     }
