@@ -434,12 +434,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
     constexpr int XV = (MT * 256 + NTH - 1) / NTH;                     // x vectors per thread per chunk
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
     const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
-    const int n = blockIdx.x * BN + w * 16 + lr;
+    const int bx = blockIdx.x;
+    const int n = bx * BN + w * 16 + lr;
     const int kbeg = split * NCK * SK_BK;
     // Row-major W: lane (lr, g) reads W[n][k + i*32 + g*8 ..+8].  TILED W (decode copy, built at load
     // time): [n-tile][k-chunk][i][lane][8] -- every wave load instruction is one contiguous 1 KiB and
     // an n-tile's whole K stream is contiguous in HBM (DRAM-page friendly).
-    const int ntile = blockIdx.x * NW + w, ntiles = (N + 15) / 16;
+    const int ntile = bx * NW + w, ntiles = (N + 15) / 16;
     const bf16* wp = TILED ? W + ((long)(ntile < ntiles ? ntile : ntiles - 1) * (K / SK_BK) + split * NCK) * 2048 + l * 8
                            : W + (long)(n < N ? n : N - 1) * K + kbeg + g * 8;
     constexpr int WCH = TILED ? 2048 : SK_BK, WI = TILED ? 512 : 32;       // element strides per chunk / per k-step
@@ -488,8 +489,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
             __syncthreads();
         }
     }
-    if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid);
-    else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * BN, w, g, lr, tid, wt);
+    if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, bx, w, g, lr, tid);
+    else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, bx * BN, w, g, lr, tid, wt);
 }
 template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false>
 static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
@@ -499,7 +500,7 @@ static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
     dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
-    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K, pg_tune->wt_store);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K, pg_tune->wt_store & 1);
 }
 template <int D, bool XDB>
 static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
@@ -620,6 +621,17 @@ constexpr int sk4_wait_count_w(int c, int NCK, int XD, int WD, int MT) {
         if (it + WD < NCK) { ops += 4; lastW[it + WD] = ops; }
     }
     return 0;
+}
+// W fragment load as OPAQUE asm: the compiler may schedule a plain load from a const __restrict__ pointer across an
+// `asm volatile("" ::: "memory")` fence (nothing can alias it), which silently changes the VMEM issue order the hand-counted vmcnt
+// waits of the v4 kernel assume -- observed as a stale 4-row x piece on a cold first launch.  asm volatile statements keep their
+// program order, so the simulated order of sk4_wait_count() is the order in the instruction stream.
+__device__ __forceinline__ void sk4_wload(bf16x8& dst, const bf16* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(p) : "memory");
+}
+// wait until at most N_ VMEM ops are outstanding; the W registers are in/out operands so no consumer of them can be scheduled above
+template <int N_> __device__ __forceinline__ void wait_vmcnt_w(bf16x8 (&wv)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]) : "n"(N_ > 63 ? 63 : N_) : "memory");
 }
 template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_ > 63 ? 63 : N_) : "memory"); }   // 6-bit field: clamping only waits longer
 
@@ -753,8 +765,7 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
 #pragma unroll
     for (int c = 0; c < WD && c < NCK; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wr[c][i] = __builtin_nontemporal_load((const bf16x8*)(wp + c * 2048 + i * 512));
-    asm volatile("" ::: "memory");
+        for (int i = 0; i < 4; ++i) sk4_wload(wr[c][i], wp + c * 2048 + i * 512);
     stamp();
     sk4_static_for<0, NCK, XD, WD, MTW>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
@@ -765,8 +776,8 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
             stamp();
             if constexpr (c + XD - 1 < NCK) issueX(c + XD - 1);
         }
-        asm volatile("" ::: "memory");
-        if (pw) { wait_vmcnt<sk4_wait_count_w(c, NCK, XD, WD, MTW)>(); stamp(); }      // profiling only: when did W(c) land?
+        wait_vmcnt_w<(ABL & 1) ? 0 : sk4_wait_count_w(c, NCK, XD, WD, MTW)>(wr[c % WD]);      // W(c) landed (younger loads stay in flight)
+        stamp();
         if constexpr (!(ABL & 2)) sk4_mfma_chunk<MTW, (EPI >= 2)>(smem + (c % XD) * XB + wm * (MTW * 4096), lr, g, wr[c % WD], acc);
         else {
 #pragma unroll
@@ -774,9 +785,8 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
         }
         if constexpr (c + WD < NCK) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wr[c % WD][i] = __builtin_nontemporal_load((const bf16x8*)(wp + (c + WD) * 2048 + i * 512));
+            for (int i = 0; i < 4; ++i) sk4_wload(wr[c % WD][i], wp + (c + WD) * 2048 + i * 512);
         }
-        asm volatile("" ::: "memory");
         stamp();
     });
     if constexpr (ABL & 4) { if (acc[0][0] == 123.456f) out[tid] = acc[0][0]; return; }
