@@ -180,7 +180,7 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     hipStream_t s; hipStreamCreate(&s);
     GemmA ga; ga.ptr = A; ga.lda = K;
     if (conv) { ga.kind = 1; ga.Hi = Hi; ga.Wi = Wi; ga.Cin = Cin; ga.up = up; ga.zeros = zeros; }
-    GemmEpi e; e.out = o0; e.out_f32 = 1; e.ldc = N;
+    GemmEpi e; e.out = o0; e.out_f32 = getenv("PG_BENCH_OUT_BF16") ? 0 : 1; e.ldc = N;      // bf16 output: timing only (verify = 0)
     PgTune tune; const PgTune* const saved = pg_tune; pg_tune = &tune;
     if (getenv("PG_CONV_HALO")) tune.conv_halo = atoi(getenv("PG_CONV_HALO"));
     hipDeviceSynchronize();

@@ -188,7 +188,7 @@ struct pg_engine {
     int prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtype, const int32_t* pad_len, int R_, int L_,
                 int pmode, void* hidden_out, int hidden_dtype, hipStream_t s);
     template <typename T> void gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, int K, bool allow_skinny, const void* Wt = nullptr);
-    template <typename T> void run_layers(hipStream_t s, int M, int mode, T* final_out);
+    template <typename T> void run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t* advance = nullptr);
     template <typename T> void head_logits(hipStream_t s, const T* in, int M);
     void forward_decode(hipStream_t s);
     int decode_image(int T, float cfgw, float temp, uint64_t seed, const int32_t* force_tok, const uint8_t* force_mask,
@@ -718,7 +718,7 @@ void pg_engine::gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, in
 // RMSNorm written to final_out (T).  Every GEMM leaves fp32 split-K slabs in ``part``; the
 // next elementwise kernel folds the reduction in (deterministic, no atomics).
 template <typename T>
-void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
+void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t* advance) {
     const int Hh = H(), I = cfg.inter, HDm = HD();
     const bool sk = mode == 0;
     int S_pend = 0; long slab_pend = 0;
@@ -791,7 +791,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out) {
         S_pend = S_last; slab_pend = slab_last;
     }
     tic(s);
-    launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps);
+    launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps, advance);
     toc(s, TC_NORM, norm_bytes(S_pend));
     tc_on = false;
 }
@@ -895,8 +895,8 @@ void pg_engine::head_logits(hipStream_t s, const T* in, int M) {
 }
 
 void pg_engine::forward_decode(hipStream_t s) {
-    if (bf) run_layers<bf16>(s, R, 0, (bf16*)hfin); else run_layers<float>(s, R, 0, (float*)hfin);
-    launch_advance(s, d_ndec);
+    // the final RMSNorm launch also advances the device step counter
+    if (bf) run_layers<bf16>(s, R, 0, (bf16*)hfin, d_ndec); else run_layers<float>(s, R, 0, (float*)hfin, d_ndec);
 }
 
 int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const int32_t* force_tok,

@@ -81,7 +81,7 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
 // partial may be null (S=0).  xn may be null (residual update only).
 template <typename T>
 void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
-                    int M, int H, float eps);
+                    int M, int H, float eps, int32_t* advance = nullptr);     // advance: *advance += 1 by one thread (decode step counter)
 // gather rows: dst fp32 [n,H] = table[ids[idx]]  (table fp32)
 void launch_embed_gather(hipStream_t s, const float* table, const int32_t* ids, const int32_t* src_idx, float* dst,
                          int n, int H, int vocab);

@@ -37,21 +37,24 @@ __device__ __forceinline__ void sum_slabs(const float* __restrict__ p, long slab
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ partial,
                                                      int S, long slab, const T* __restrict__ w,
-                                                     T* __restrict__ xn, int H, float eps) {
+                                                     T* __restrict__ xn, int H, float eps, int32_t* __restrict__ advance) {
     __shared__ float red[4];
     rmsnorm_row<T, NV>(blockIdx.x, x, partial, S, slab, w, xn, H, eps, red);
+    // the decode step's LAST kernel also advances the device step counter (no kernel of the step reads it after this
+    // point; saves the 1-thread advance launch of every step)
+    if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
 }
 template <typename T>
 void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
-                    int M, int H, float eps) {
+                    int M, int H, float eps, int32_t* advance) {
     if (M <= 0) return;
-    if (H <= 1024) hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps);
-    else if (H <= 2048) hipLaunchKernelGGL((rmsnorm_kernel<T, 2>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps);
-    else if (H <= 4096) hipLaunchKernelGGL((rmsnorm_kernel<T, 4>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps);
-    else hipLaunchKernelGGL((rmsnorm_kernel<T, 8>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps);
+    if (H <= 1024) hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
+    else if (H <= 2048) hipLaunchKernelGGL((rmsnorm_kernel<T, 2>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
+    else if (H <= 4096) hipLaunchKernelGGL((rmsnorm_kernel<T, 4>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
+    else hipLaunchKernelGGL((rmsnorm_kernel<T, 8>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
 }
-template void launch_rmsnorm<float>(hipStream_t, float*, const float*, int, long, const float*, float*, int, int, float);
-template void launch_rmsnorm<bf16>(hipStream_t, float*, const float*, int, long, const bf16*, bf16*, int, int, float);
+template void launch_rmsnorm<float>(hipStream_t, float*, const float*, int, long, const float*, float*, int, int, float, int32_t*);
+template void launch_rmsnorm<bf16>(hipStream_t, float*, const float*, int, long, const bf16*, bf16*, int, int, float, int32_t*);
 
 // ------------------------------------------------------------------------------- row movers
 // dst[t] = table[ids[src_idx ? src_idx[t] : t]]   (K1; packed left-pad-free gather)
