@@ -724,15 +724,16 @@ template <int C, int NCK, int XD, int WD, int MT, class F> __device__ __forceinl
 // MS = 2: 8 waves per block, wave w = (n-tile w & 3, row half w >> 2): two waves per SIMD, so one wave's LDS fragment
 // reads run under the other's MFMAs (measured with 4 lock-stepped waves: reads and MFMAs of a chunk serialise,
 // ~1050 cycles per chunk instead of ~550).  Both row halves load the same W fragments (second one hits L1/L2).
-template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>      // ABL (bench only): 1 no x DMA / barriers, 2 no MFMA, 4 no stores
+template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>      // ABL (bench only): 1 no x DMA / barriers, 2 no MFMA, 4 no stores, 32 per-wave s_memtime stamps
 __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
                                                                float* __restrict__ out, int M, int N, int K, unsigned long long* prof) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MTW = MT / MS;                                     // m-tiles per wave
     // tuning aid: per-wave s_memtime stamps (prof != nullptr only from the microbenchmark): 64 slots per wave
+    constexpr bool PROF = (ABL & 32) != 0;
     int pslot = 0;
-    unsigned long long* pw = prof ? prof + ((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (4 * MS) + (threadIdx.x >> 6)) * 64 : nullptr;
-    auto stamp = [&]() { if (pw && (threadIdx.x & 63) == 0 && pslot < 64) pw[pslot] = __builtin_readcyclecounter(); ++pslot; };
+    unsigned long long* pw = (PROF && prof) ? prof + ((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (4 * MS) + (threadIdx.x >> 6)) * 64 : nullptr;
+    auto stamp = [&]() { if constexpr (PROF) { if (pw && (threadIdx.x & 63) == 0 && pslot < 64) pw[pslot] = __builtin_readcyclecounter(); ++pslot; } };
     stamp();
     constexpr int XB = MT * 16 * 256;                                // bytes per x chunk slot
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, lr = l & 15;
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
     else if constexpr (EPI == 4) sk4_store_direct<MTW, true>(acc, out + (long)split * M * N, M, N, mb, ntile * 16, g, lr);
     else if constexpr (EPI == 1) { static_assert(EPI != 1 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_swiglu<MT, 4>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid); }
     else { static_assert(EPI != 0 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_tile<MT, 4>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid); }
-    if (pw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); }
+    if constexpr (PROF) { if (pw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); } }
 }
 unsigned long long* g_sk4_prof = nullptr;       // microbenchmark only
 template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
@@ -842,6 +843,8 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 50: return sk3_prod_nck<8, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W layout
         case 51: return sk3_prod_nck<4, 0, 4, true>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // tiled W, 64-row M blocks
         // v4 (x by LDS-DMA): MT / x ring depth / W ring depth / min blocks per CU
+        case 271: return sk4_nck<4, 3, 3, 4, 2, 32>(s, x, W, out, M, N, K, S) ? 128 : 0;    // stamped (tools/sk4_profile.py): 64-row blocks
+        case 274: return sk4_nck<8, 3, 3, 4, 1, 32>(s, x, W, out, M, N, K, S) ? 128 : 0;    // stamped: 128-row blocks
         case 71: return sk4_nck<4, 3, 3, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 74: return sk4_nck<8, 3, 3, 0, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 160: return sk4_nck<2, 4, 3, 4, 4>(s, x, W, out, M, N, K, S) ? 128 : 0;        // 32-row blocks

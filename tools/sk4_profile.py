@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of one decode-GEMM launch (s_memtime stamps).  usage: sk4_profile.py variant S [shape]"""
+"""Per-wave timeline of one decode-GEMM launch (s_memtime stamps).  usage: sk4_profile.py variant S [shape]
+variants with stamps compiled in: 271 (64-row blocks), 274 (128-row blocks)."""
 import ctypes as C, os, sys
 import numpy as np
 import torch  # noqa
