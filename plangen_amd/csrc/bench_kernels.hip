@@ -1,3 +1,5 @@
+#include <cstdio>
+#include <cstdlib>
 // Microbenchmarks of individual kernels inside the library (HIP events on the launch stream,
 // weights rotated through > 256 MiB so the Infinity Cache cannot hold them).  Tuning aid only.
 #include <hip/hip_runtime.h>
@@ -6,6 +8,7 @@
 #include <vector>
 #include "../../include/plangen_hip.h"
 #include "kernels.h"
+#include "gemm_common.h"
 
 __global__ void fill_bf16_kernel(bf16* p, long n, uint32_t seed) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -15,6 +18,17 @@ __global__ void fill_bf16_kernel(bf16* p, long n, uint32_t seed) {
     }
 }
 
+// pattern operands for race forensics: x[m][k] = (1 + m/128) * 2^(k/128 - 8), W = 1/128: every (row, k-chunk) contributes a distinct exact
+// term, so a wrong output identifies which chunk's x piece was replaced by which
+__global__ void fill_pattern_x_kernel(bf16* p, int M, int K) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)M * K; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / K), c = (int)(i % K) / 128;
+        ET<bf16>::st(p + i, (1.f + (float)(m & 127) / 128.f) * exp2f((float)(c & 15) - 8.f));
+    }
+}
+__global__ void fill_const_kernel(bf16* p, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) ET<bf16>::st(p + i, v);
+}
 extern "C" int pg_bench_skinny(int M, int N, int K, int variant, int S, int iters, int with_consumer, float* us_out) {
     const long wbytes = (long)N * K * 2;
     int nbuf = (int)((600L << 20) / wbytes) + 1; if (nbuf > 64) nbuf = 64; if (nbuf < 2) nbuf = 2;
@@ -55,16 +69,25 @@ __global__ void reduce_slabs_kernel(const float* p, int S, long slab, float* o) 
         o[i] = a;
     }
 }
+__global__ void save_if_bad_kernel(const float* r1, float* save, long n, const float* md, float tol, int* flag, int rep);
 extern "C" int pg_bench_skinny_verify(int M, int N, int K, int variant, int S, int tiled, int reps, float* maxdiff, float* maxref) {
     bf16 *x, *W, *Wt; float *o0, *o1, *r0, *r1, *md;
     hipMalloc((void**)&x, (long)M * K * 2); hipMalloc((void**)&W, (long)N * K * 2); hipMalloc((void**)&Wt, (long)N * K * 2);
     hipMalloc((void**)&o0, (long)S * M * N * 4); hipMalloc((void**)&o1, (long)S * M * N * 4);
     hipMalloc((void**)&r0, (long)M * N * 4); hipMalloc((void**)&r1, (long)M * N * 4); hipMalloc((void**)&md, 8);
-    hipLaunchKernelGGL(fill_bf16_kernel, dim3(256), dim3(256), 0, 0, x, (long)M * K, 3u);
-    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
+    const bool pattern = getenv("PG_VERIFY_PATTERN") != nullptr;
+    if (pattern) {
+        hipLaunchKernelGGL(fill_pattern_x_kernel, dim3(256), dim3(256), 0, 0, x, M, K);
+        hipLaunchKernelGGL(fill_const_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 1.f / 128.f);
+    } else {
+        hipLaunchKernelGGL(fill_bf16_kernel, dim3(256), dim3(256), 0, 0, x, (long)M * K, 3u);
+        hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u);
+    }
     launch_tile_weights(0, W, Wt, N, K);
     hipMemset(md, 0, 8);
     int rc = 0;
+    float* vsave = nullptr; int* vflag = nullptr;
+    if (getenv("PG_VERIFY_SAVE")) { hipMalloc((void**)&vsave, (long)M * N * 4); hipMalloc((void**)&vflag, 8); hipMemset(vflag, 0, 8); }
     launch_gemm_skinny_variant(0, 1, x, W, o0, M, N, K, S);
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1024), dim3(256), 0, 0, o0, S, (long)M * N, r0);
     hipMemset(r1, 0, (long)M * N * 4);
@@ -74,11 +97,109 @@ extern "C" int pg_bench_skinny_verify(int M, int N, int K, int variant, int S, i
         if (!launch_gemm_skinny_variant(0, variant, x, tiled ? Wt : W, o1, M, N, K, S)) { rc = -1; break; }
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1024), dim3(256), 0, 0, o1, S, (long)M * N, r1);
         hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, 0, r0, r1, (long)M * N, md);
+        if (vsave) hipLaunchKernelGGL(save_if_bad_kernel, dim3(256), dim3(256), 0, 0, r1, vsave, (long)M * N, md, pattern ? 1e-3f : 2e-3f * 0.047f, vflag, rep);
     }
     hipDeviceSynchronize();
     if (hipGetLastError() != hipSuccess) rc = -2;
     float h[2] = {0, 0}; hipMemcpy(h, md, 8, hipMemcpyDeviceToHost);
+    if (vsave) {
+        int hf[2]; hipMemcpy(hf, vflag, 8, hipMemcpyDeviceToHost);
+        if (hf[0]) {
+            std::vector<float> a((size_t)M * N), b((size_t)M * N);
+            hipMemcpy(a.data(), r0, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), vsave, b.size() * 4, hipMemcpyDeviceToHost);
+            const float tol = 2e-3f * h[1];
+            fprintf(stderr, "[verify] v%d N=%d S=%d first bad launch %d; wrong (row: n-tiles) =", variant, N, S, hf[1]);
+            for (int r = 0; r < M; ++r) {
+                int cnt = 0, lo = -1, hi = -1;
+                for (int ct = 0; ct < N / 16; ++ct) {
+                    bool wrong = false;
+                    for (int j = 0; j < 16; ++j) wrong |= !(fabsf(a[(long)r * N + ct * 16 + j] - b[(long)r * N + ct * 16 + j]) <= tol);
+                    if (wrong) { ++cnt; if (lo < 0) lo = ct; hi = ct; }
+                }
+                if (cnt) fprintf(stderr, " %d:%d[%d..%d] got-ref=%.6f ref=%.6f", r, cnt, lo, hi, b[(long)r * N + lo * 16] - a[(long)r * N + lo * 16], a[(long)r * N + lo * 16]);
+            }
+            fprintf(stderr, "\n");
+        }
+        hipFree(vsave); hipFree(vflag);
+    }
     if (maxdiff) *maxdiff = h[0]; if (maxref) *maxref = h[1];
+    hipFree(x); hipFree(W); hipFree(Wt); hipFree(o0); hipFree(o1); hipFree(r0); hipFree(r1); hipFree(md);
+    return rc;
+}
+
+__global__ void save_if_bad_kernel(const float* r1, float* save, long n, const float* md, float tol, int* flag, int rep) {
+    if (!(*md > tol) || (flag[0] != 0 && flag[1] != rep)) return;          // first bad launch only (stream order: one launch decides at a time)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { flag[1] = rep; }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) save[i] = r1[i];
+    __syncthreads();
+    if (threadIdx.x == 0) atomicExch(&flag[0], 1);
+}
+// Diagnostic form of the screen: synchronous per-launch compare; reports the number of bad launches and, for the first one,
+// up to ``cap`` (row, col) positions of wrong elements (tolerance 2e-3 of max |ref|).  x / W are re-randomised per batch by ``seed``.
+extern "C" int pg_bench_skinny_diag(int M, int N, int K, int variant, int S, int reps, unsigned seed, int* bad_launches, int* pos, int cap, int* npos) {
+    bf16 *x, *W, *Wt; float *o0, *o1, *r0, *r1, *md;
+    hipMalloc((void**)&x, (long)M * K * 2); hipMalloc((void**)&W, (long)N * K * 2); hipMalloc((void**)&Wt, (long)N * K * 2);
+    hipMalloc((void**)&o0, (long)S * M * N * 4); hipMalloc((void**)&o1, (long)S * M * N * 4);
+    hipMalloc((void**)&r0, (long)M * N * 4); hipMalloc((void**)&r1, (long)M * N * 4); hipMalloc((void**)&md, 8);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(256), dim3(256), 0, 0, x, (long)M * K, 3u + seed);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, W, (long)N * K, 7u + seed);
+    launch_tile_weights(0, W, Wt, N, K);
+    launch_gemm_skinny_variant(0, 1, x, W, o0, M, N, K, S);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1024), dim3(256), 0, 0, o0, S, (long)M * N, r0);
+    hipMemset(r1, 0, (long)M * N * 4); hipMemset(md, 0, 8);
+    hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, 0, r0, r1, (long)M * N, md + 1);
+    const bool async = getenv("PG_DIAG_ASYNC") != nullptr;
+    float h[2] = {0.f, 0.047f};
+    if (!(async && getenv("PG_DIAG_NOSYNC"))) hipMemcpy(h, md, 8, hipMemcpyDeviceToHost);       // NOSYNC: the loop follows the reference launches with no host sync (fixed-seed max |ref| = 0.047)
+    const float tol = 2e-3f * h[1];
+    int rc = 0, bad = 0, np = 0;
+    std::vector<float> a((size_t)M * N), b((size_t)M * N);
+    float *mdr = nullptr, *save = nullptr; int* flag = nullptr;
+    if (async) {
+        hipMalloc((void**)&mdr, reps * 4); hipMemset(mdr, 0, reps * 4); hipMalloc((void**)&save, (long)M * N * 4); hipMalloc((void**)&flag, 8); hipMemset(flag, 0, 8);
+        for (int rep = 0; rep < reps; ++rep) {
+            if (getenv("PG_DIAG_SYNCSET")) hipMemset(o1, 0xff, (long)S * M * N * 4); else hipMemsetAsync(o1, 0xff, (long)S * M * N * 4, 0);
+            if (!launch_gemm_skinny_variant(0, variant, x, Wt, o1, M, N, K, S)) { rc = -1; break; }
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1024), dim3(256), 0, 0, o1, S, (long)M * N, r1);
+            hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, 0, r0, r1, (long)M * N, mdr + rep);
+            hipLaunchKernelGGL(save_if_bad_kernel, dim3(256), dim3(256), 0, 0, r1, save, (long)M * N, mdr + rep, tol, flag, rep);
+        }
+        hipDeviceSynchronize();
+        std::vector<float> hm(reps); hipMemcpy(hm.data(), mdr, reps * 4, hipMemcpyDeviceToHost);
+        int hf[2]; hipMemcpy(hf, flag, 8, hipMemcpyDeviceToHost);
+        for (int rep = 0; rep < reps; ++rep) bad += !(hm[rep] <= tol);
+        if (bad) {
+            hipMemcpy(a.data(), r0, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), save, b.size() * 4, hipMemcpyDeviceToHost);
+            // summary: (-2, rep) for every bad launch, then one (row, 16-column tile) entry per tile of the first bad launch that holds a wrong element
+            for (int rep = 0; rep < reps && np < cap; ++rep) if (!(hm[rep] <= tol)) { pos[np * 2] = -2; pos[np * 2 + 1] = rep; ++np; }
+            for (int r = 0; r < M; ++r)
+                for (int ct = 0; ct < N / 16 && np < cap; ++ct) {
+                    bool wrong = false;
+                    for (int j = 0; j < 16; ++j) wrong |= !(fabsf(a[(long)r * N + ct * 16 + j] - b[(long)r * N + ct * 16 + j]) <= tol);
+                    if (wrong) { pos[np * 2] = r; pos[np * 2 + 1] = ct; ++np; }
+                }
+            if (np < cap) { pos[np * 2] = -1; pos[np * 2 + 1] = hf[1]; ++np; }
+        }
+        hipFree(mdr); hipFree(save); hipFree(flag);
+    }
+    for (int rep = 0; rep < reps && !async; ++rep) {
+        hipMemsetAsync(o1, 0xff, (long)S * M * N * 4, 0); hipMemsetAsync(md, 0, 4, 0);
+        if (!launch_gemm_skinny_variant(0, variant, x, Wt, o1, M, N, K, S)) { rc = -1; break; }
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(1024), dim3(256), 0, 0, o1, S, (long)M * N, r1);
+        hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, 0, r0, r1, (long)M * N, md);
+        hipMemcpy(h, md, 4, hipMemcpyDeviceToHost);
+        if (!(h[0] <= tol)) {
+            if (bad++ == 0) {
+                hipMemcpy(a.data(), r0, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), r1, b.size() * 4, hipMemcpyDeviceToHost);
+                for (long i = 0; i < (long)M * N && np < cap; ++i)
+                    if (!(fabsf(a[i] - b[i]) <= tol)) { pos[np * 2] = (int)(i / N); pos[np * 2 + 1] = (int)(i % N); ++np; }
+                if (np < cap) { pos[np * 2] = -1; pos[np * 2 + 1] = rep; ++np; }
+            }
+        }
+    }
+    hipDeviceSynchronize();
+    if (hipGetLastError() != hipSuccess) rc = -2;
+    if (bad_launches) *bad_launches = bad; if (npos) *npos = np;
     hipFree(x); hipFree(W); hipFree(Wt); hipFree(o0); hipFree(o1); hipFree(r0); hipFree(r1); hipFree(md);
     return rc;
 }
@@ -207,5 +328,59 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     const int rc = hipGetLastError() == hipSuccess ? 0 : -1;
     hipFree(A); hipFree(Wt); hipFree(zeros); hipFree(o0); if (o1) hipFree(o1); hipFree(md);
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ordering probe: does a YOUNGER register load retire (vmcnt) before an OLDER LDS-DMA load of the same wave has landed in LDS?
+// Per iteration and wave: sentinel -> own LDS slot; LDS-DMA of a cold 1 KiB line set (never touched before); register load of a hot
+// line (same address every iteration); s_waitcnt vmcnt(1); ds_read of the slot.  A sentinel read = the counted wait was satisfied by
+// the younger load.  mode bit 0: hot load is nt; bit 1: order reversed (register load older, DMA younger, vmcnt(1) then check the
+// REGISTER value instead -- the control).
+__global__ __launch_bounds__(256) void dma_order_kernel(const unsigned* __restrict__ cold, const unsigned* __restrict__ hot, int iters, long stride_words,
+                                                        int mode, unsigned* __restrict__ fails, unsigned* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) unsigned lds[4][256];
+    __shared__ __attribute__((aligned(16))) unsigned lds2[4][256];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + w;
+    unsigned bad = 0, acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned* src = cold + ((long)it * gridDim.x * 4 + wave) * stride_words + l * 4;
+        *(uint4*)&lds[w][l * 4] = make_uint4(0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u32x4 hv;
+        glds16(src, (char*)&lds[w][0]);
+        if (mode & 4) { hv = (u32x4){0, 0, 0, 0}; glds16(hot + l * 4, (char*)&lds2[w][0]); }              // younger op is a second LDS-DMA (hot line) instead of a register load
+        else if (mode & 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(hv) : "v"(hot + l * 4) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(hv) : "v"(hot + l * 4) : "memory");
+        if (mode & 8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");      // 8: positive control (no wait at all)
+        u32x4 got;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(got) : "v"((unsigned)(size_t)&lds[w][l * 4]) : "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(hv) :: "memory");
+        const unsigned idx = (unsigned)(((long)it * gridDim.x * 4 + wave) * stride_words + l * 4);
+        bad += (got[0] != idx * 2654435761u) || (got[3] != (idx + 3) * 2654435761u);
+        acc += hv[0];
+    }
+    bad = __builtin_amdgcn_readfirstlane(__popcll(__ballot(bad != 0)) ? 1 : 0) * 0 + bad;
+    if (bad) atomicAdd(fails, bad);
+    if (acc == 0x12345u) sink[0] = acc;
+}
+__global__ void fill_hash_kernel(unsigned* p, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = (unsigned)i * 2654435761u;
+}
+extern "C" int pg_bench_dma_order(int blocks, int iters, int mode, unsigned* fails_out, unsigned* checks_out) {
+    const long stride_words = 1024;                 // 4 KiB apart: every DMA touches fresh lines (and pages)
+    const long n = (long)iters * blocks * 4 * stride_words;
+    unsigned *cold, *hot, *fails, *sink;
+    if (hipMalloc((void**)&cold, n * 4) != hipSuccess) return -3;
+    hipMalloc((void**)&hot, 4096); hipMalloc((void**)&fails, 4); hipMalloc((void**)&sink, 4);
+    hipLaunchKernelGGL(fill_hash_kernel, dim3(2048), dim3(256), 0, 0, cold, n);
+    hipMemset(hot, 1, 4096); hipMemset(fails, 0, 4);
+    hipLaunchKernelGGL(dma_order_kernel, dim3(blocks), dim3(256), 0, 0, cold, hot, iters, stride_words, mode, fails, sink);
+    hipDeviceSynchronize();
+    int rc = hipGetLastError() == hipSuccess ? 0 : -2;
+    unsigned h = 0; hipMemcpy(&h, fails, 4, hipMemcpyDeviceToHost);
+    if (fails_out) *fails_out = h; if (checks_out) *checks_out = (unsigned)((long)blocks * 4 * 64 * iters);
+    hipFree(cold); hipFree(hot); hipFree(fails); hipFree(sink);
     return rc;
 }

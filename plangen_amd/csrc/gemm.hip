@@ -827,10 +827,12 @@ static bool sk4_nck(hipStream_t s, const bf16* x, const bf16* Wt, float* out, in
 
 void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
 // variant table for the microbenchmark (tools/skinny_sweep.py): returns BK (0 = unsupported)
+static bool launch_gemm_skinny_tiled_only(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S);
 int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
     switch (variant) {
         case 0: launch_gemm_skinny(s, x, W, out, M, N, K, S, nullptr); return 128;         // production, row-major W (v3, falls back to v1)
         case 1: launch_gemm_skinny_v1(s, x, W, out, M, N, K, S); return 128;               // v1: 1-deep prefetch
+        case 2: return launch_gemm_skinny_tiled_only(s, x, W, out, M, N, K, S) ? 128 : 0;   // production dispatch on the TILED decode copy
         case 20: return sk3_dispatch<2, true>(s, x, W, out, M, N, K, S) ? 128 : 0;         // v3 ring 2, x double-buffered
         case 24: return sk3_prod_nck<4, 0>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;   // 64-row M blocks (grid.z = M/64)
         case 40: {   // MFMA tile kernel (128x128x64, glds) with split-K expressed through the batch strides
@@ -907,6 +909,9 @@ void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out,
     if (sk4_prod<4>(s, x, Wt, out, M, N, K, S)) return;
     if (Wt && sk3_prod_tiled<0, true>(s, x, Wt, out, M, N, K, S)) return;
     if (!sk3_prod<0>(s, x, W, out, M, N, K, S)) launch_gemm_skinny_v1(s, x, W, out, M, N, K, S);
+}
+static bool launch_gemm_skinny_tiled_only(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+    return sk4_prod<4>(s, x, Wt, out, M, N, K, S) || sk3_prod_tiled<0, true>(s, x, Wt, out, M, N, K, S);
 }
 // gate|up GEMM with the SwiGLU gate fused (S = 1): h bf16 [M, N/2].  Returns false when the
 // shape has no fused instantiation (caller falls back to slabs + silu_mul kernel).

@@ -249,3 +249,20 @@ def test_stream_gemm_is_deterministic_under_repetition(tiny_cfg, tiny_weights, M
     assert (first.cpu().double() - ref).abs().max().item() < 2e-4 * ref.abs().max().item() + 1e-4
     for _ in range(60):
         assert torch.equal(e.op_gemm(a, w, 4), first)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(128, 6144, 2048, 2), (128, 2048, 2048, 4), (128, 11264, 2048, 2), (128, 2048, 5632, 4),
+                                     (64, 6144, 2048, 2), (32, 2048, 5632, 4), (16, 6144, 2048, 4), (16, 2048, 2048, 8)])
+def test_decode_gemm_back_to_back_race_screen(M, N, K, S):
+    """The production decode-GEMM dispatch (tiled weight copy) launched back to back with NO host sync between launches -- the
+    harness that exposed a hazard of two co-resident 512-thread LDS-DMA blocks (profiles/r02_d_*) while synchronous
+    per-launch checks stayed clean.  Every launch of 4 x 100 must match the 1-deep reference kernel."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_hip.so"))
+    lib.pg_bench_skinny_verify.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float)] * 2
+    for _ in range(4):
+        md, mr = C.c_float(0), C.c_float(0)
+        rc = lib.pg_bench_skinny_verify(M, N, K, 2, S, 1, 100, C.byref(md), C.byref(mr))
+        assert rc == 0
+        assert md.value <= 2e-3 * mr.value, (md.value, mr.value)

@@ -9,11 +9,12 @@ M, reps = int(sys.argv[1]), int(sys.argv[2])
 for v in [int(a) for a in sys.argv[3:]]:
     for name, (N, K, Ss) in {"qkv": (6144, 2048, (2, 4)), "o": (2048, 2048, (4, 8)), "gu": (11264, 2048, (1, 2)), "down": (2048, 5632, (4, 11))}.items():
         for S in Ss:
-            bad = 0
+            bad = 0; vals = []
             for trial in range(8):
                 md, mr = C.c_float(0), C.c_float(0)
                 rc = lib.pg_bench_skinny_verify(M, N, K, v, S, 1, reps, C.byref(md), C.byref(mr))
                 if rc != 0:
                     bad = -1; break
                 bad += md.value > 2e-3 * mr.value
-            print(f"M={M} v{v} {name} S={S}: {'unsupported' if bad < 0 else f'{bad}/8 batches of {reps} launches had a wrong element'}", flush=True)
+                if md.value > 2e-3 * mr.value: vals.append((md.value, mr.value))
+            print(f"M={M} v{v} {name} S={S}: {'unsupported' if bad < 0 else f'{bad}/8 batches of {reps} launches had a wrong element'} {vals if bad > 0 else ''}", flush=True)
