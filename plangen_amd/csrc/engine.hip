@@ -1086,7 +1086,7 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
         if (bf) gemm_llm<bf16>(ws, (const bf16*)hfin, (const bf16*)lm_head, B, cfg.vocab, H(), true, lm_head_t);
         else gemm_llm<float>(ws, (const float*)hfin, (const float*)lm_head, B, cfg.vocab, H(), true);
         ta.logits_partial = part; ta.S = S_last; ta.slab = slab_last;
-        launch_text_argmax(ws, ta, B);
+        launch_text_argmax(ws, ta, B, cfg_pv, cfg_pi);
         if (with_forward) forward_decode(ws);
     };
     for (int step_i = 0; step_i < max_new; ++step_i) {

@@ -164,7 +164,7 @@ struct TextArgs {
     const float* embed_table; float* x; int H; const int32_t* n_dec;
 };
 void launch_set_text_params(hipStream_t s, TextParams* dst, TextParams v);
-void launch_text_argmax(hipStream_t s, const TextArgs& a, int B);
+void launch_text_argmax(hipStream_t s, const TextArgs& a, int B, float* scratch_v, int* scratch_i);   // scratch: B * 16 entries each
 void launch_advance(hipStream_t s, int32_t* n_dec);
 void launch_rows_differ(hipStream_t s, const int32_t* ids, int L, int first, int stride, int ref, int n, int from, int32_t* flag);
 void launch_uniform_from_bits(hipStream_t s, const uint64_t* z, float* out, int n);

@@ -630,19 +630,35 @@ void launch_cfg_sample(hipStream_t s, const SampleArgs& a, int B, float* scratch
 }
 
 // greedy text token (HF generate, do_sample=False): argmax over vocab, finished rows emit
-// eos, unfinished &= (tok != eos).
-__global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a) {
-    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int s_tok;
-    const int b = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
-    const int eos = a.p->eos, min_new = a.p->min_new, max_new = a.p->max_new;
+// eos, unfinished &= (tok != eos).  Two stages like the image sampler: grid (CFG_CHUNKS, B) scans V/CFG_CHUNKS logits with
+// 16-byte loads (split-K slabs summed in slab order), one block per row combines the winners (lowest index on ties =
+// torch.argmax), does the EOS bookkeeping and gathers the next embedding.  (One block per row over 102 400 logits with
+// scalar loads was 160 us per step at 64 rows; this pair is ~10.)
+__global__ __launch_bounds__(256) void text_scan_kernel(TextArgs a, float* __restrict__ pv, int* __restrict__ pi) {
+    __shared__ float sv[4]; __shared__ int si[4];
+    const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, step = *a.n_dec;
+    const int ban = step < a.p->min_new ? a.p->eos : -1;
+    const int chunk = ((a.V + CFG_CHUNKS * 4 - 1) / (CFG_CHUNKS * 4)) * 4;
+    const int v0 = ch * chunk, v1 = v0 + chunk < a.V ? v0 + chunk : a.V;
+    const float* lp = a.logits_partial + (long)b * a.V;
     float best = -INFINITY; int bi = 0x7fffffff;
-    for (int v = tid; v < a.V; v += 256) {
-        float c1[1] = {0.f};
-        const int oc1[1] = {0};
-        sum_slabs<1>(a.logits_partial + (long)b * a.V + v, a.slab, a.S, oc1, c1);
-        float c = c1[0];
-        if (v == eos && step < min_new) c = -INFINITY;
-        if (c > best) { best = c; bi = v; }
+    if (((a.V | (int)(a.slab & 3)) & 3) == 0) {
+        for (int v = v0 + tid * 4; v < v1; v += 1024) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < a.S; ++s) c += *(const f32x4*)(lp + (long)s * a.slab + v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cj = (v + j == ban) ? -INFINITY : c[j];
+                if (cj > best) { best = cj; bi = v + j; }
+            }
+        }
+    } else {
+        for (int v = v0 + tid; v < v1; v += 256) {
+            float c = 0.f;
+            for (int s = 0; s < a.S; ++s) c += lp[(long)s * a.slab + v];
+            if (v == ban) c = -INFINITY;
+            if (c > best) { best = c; bi = v; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -654,6 +670,17 @@ __global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a) {
     if (tid == 0) {
         float v = sv[0]; int i = si[0];
         for (int k = 1; k < 4; ++k) argmax_combine(v, i, sv[k], si[k]);
+        pv[b * CFG_CHUNKS + ch] = v; pi[b * CFG_CHUNKS + ch] = i;
+    }
+}
+__global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a, const float* __restrict__ pv, const int* __restrict__ pi) {
+    __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, step = *a.n_dec;
+    if (tid == 0) {
+        const int eos = a.p->eos, max_new = a.p->max_new;
+        float v = pv[b * CFG_CHUNKS]; int i = pi[b * CFG_CHUNKS];
+        for (int k = 1; k < CFG_CHUNKS; ++k) argmax_combine(v, i, pv[b * CFG_CHUNKS + k], pi[b * CFG_CHUNKS + k]);
+        if (i == 0x7fffffff) i = 0;                                   // every logit -inf / NaN: index 0 (torch.argmax)
         const int unf = a.unfinished[b];
         const int tok = unf ? i : eos;
         if (step < max_new) a.out[(long)b * max_new + step] = tok;
@@ -667,8 +694,9 @@ __global__ __launch_bounds__(256) void text_argmax_kernel(TextArgs a) {
     float* x0 = a.x + (long)b * a.H;
     for (int i = tid * 4; i < a.H; i += 1024) *(f32x4*)(x0 + i) = *(const f32x4*)(src + i);
 }
-void launch_text_argmax(hipStream_t s, const TextArgs& a, int B) {
-    hipLaunchKernelGGL(text_argmax_kernel, dim3(B), dim3(256), 0, s, a);
+void launch_text_argmax(hipStream_t s, const TextArgs& a, int B, float* scratch_v, int* scratch_i) {
+    hipLaunchKernelGGL(text_scan_kernel, dim3(CFG_CHUNKS, B), dim3(256), 0, s, a, scratch_v, scratch_i);
+    hipLaunchKernelGGL(text_argmax_kernel, dim3(B), dim3(256), 0, s, a, scratch_v, scratch_i);
 }
 
 // test tap: the sampler's uniform / Gumbel transform of raw 64-bit RNG outputs: out[i] = u, out[n+i] = -log(-log(u))
