@@ -200,6 +200,9 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *   attn_variant, attn_waves (0; 4 pins 4-wave blocks)   decode-attention kernel variants
  *   gemm256 (1)         256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)
  *   conv_halo (1)       direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: off)
+ *   gn_fuse (1)         GroupNorm statistics from the producing convolution's epilogue (halo-tile convolutions)
+ *   vq_mid_bf16 (1)     bf16 mode: the tensor between a ResnetBlock's two convolutions is bf16 (statistics from the fp32
+ *                       accumulators); 0 keeps it fp32 like the skip stream
  *   force_swiglu (1)    SwiGLU fused into the decode gate|up GEMM at every batch size
  *   split_target_small / _mid / _big (128 / 256 / 128)   decode split-K block-count targets by row count
  * Returns PG_ERR_ARG for an unknown key. */

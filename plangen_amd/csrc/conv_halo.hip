@@ -242,7 +242,7 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
         if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS); attr = true; } \
         hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, H, Wd, gn_part);  \
     }
-    if (gn_part && !(e.out_f32 && (e.ldc & 3) == 0)) gn_part = nullptr;
+    if (gn_part && (e.ldc & 3) != 0) gn_part = nullptr;
     if (gn_nsplit) *gn_nsplit = gn_part ? (H / CH_TH) * (Wd / CH_TW) : 0;
     if (pg_tune->conv_halo == 2) { if (a.up) CH_LAUNCH(false, true) else CH_LAUNCH(false, false) }
     else { if (a.up) CH_LAUNCH(true, true) else CH_LAUNCH(true, false) }

@@ -126,7 +126,7 @@ struct pg_engine {
     hipGraphExec_t gexec = nullptr; std::vector<int64_t> gkey;
     hipGraphExec_t gexec_txt = nullptr; std::vector<int64_t> gkey_txt;      // text-decode step (lm_head + argmax + stack)
     void drop_graphs() { if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; } if (gexec_txt) { (void)hipGraphExecDestroy(gexec_txt); gexec_txt = nullptr; } }
-    bool use_graph = true; bool time_attn = false; bool fuse_rope = true; bool force_swiglu = true; bool gn_fuse = true; int cu_split = 0;
+    bool use_graph = true; bool time_attn = false; bool fuse_rope = true; bool force_swiglu = true; bool gn_fuse = true; bool mid_bf16 = true; int cu_split = 0;
     // per-kernel-class HIP-event timing of the decode loop (eager instrumented pass, pg_set_option("time_attn", 1)):
     // one event pair per launch group on the launch stream, on every ``time_stride``-th decode step
     enum { TC_ATTN = 0, TC_QKV, TC_O, TC_GU, TC_DOWN, TC_NORM, TC_HEAD, TC_SAMPLE, TC_EMPTY, TC_N };
@@ -198,11 +198,11 @@ struct pg_engine {
     int text_greedy(int max_new, int min_new, int eos, int64_t* out, int* out_len, hipStream_t s);
     template <typename T> int vq_decode(const int32_t* codes, void* img_out, int out_dtype, int B, hipStream_t s);
     template <typename T> int vq_encode(const void* img, int img_dtype, int64_t* idx, int B, hipStream_t s);
-    template <typename T> void conv3(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual, int res_f32, int B, int Hi, int Wi, int up, int stride2);
+    template <typename T> void conv3(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual, int res_f32, int B, int Hi, int Wi, int up, int stride2, int feeds_gn = -1);
     template <typename T> void conv1(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual, int res_f32, long M);
     template <typename T> void resblock(hipStream_t s, const ResBlockW& r, int B, int Hs, int Ws);
     template <typename T> void attnblock(hipStream_t s, const AttnW& a, int B, int HW);
-    template <typename T> void gn(hipStream_t s, const NormW& n, const float* in, T* out, int B, int HW, int swish);
+    template <typename T, typename TI = float> void gn(hipStream_t s, const NormW& n, const TI* in, T* out, int B, int HW, int swish);
     int fetch_timing();
     void destroy();
 };
@@ -1133,23 +1133,24 @@ int pg_engine::text_greedy(int max_new, int min_new, int eos, int64_t* out, int*
 // conv outputs feeding a GroupNorm, shortcut outputs) are fp32; conv / GEMM inputs (GroupNorm
 // outputs, attention operands) are T.  Keeping the skip stream in fp32 removes the largest
 // bf16 error term (measured offline: 5.6e-5 of the 1e-4 pixel-MSE budget).
-template <typename T>
-void pg_engine::gn(hipStream_t s, const NormW& n, const float* in, T* out, int B, int HW, int swish) {
+template <typename T, typename TI>
+void pg_engine::gn(hipStream_t s, const NormW& n, const TI* in, T* out, int B, int HW, int swish) {
     // statistics already produced by the convolution that wrote ``in`` (conv_halo epilogue)?
     if (gn_part_of == (const void*)in && gn_part_n > 0 && gn_part_b == B) launch_gn_finalize(s, gn_ws, gn_stats, gn_coef, n.g, n.b, B, gn_part_n, HW, n.c, 1e-6f);
-    else launch_gn_stats(s, in, 0, gn_stats, gn_ws, B, HW, n.c, 1e-6f, gn_coef, n.g, n.b);
+    else launch_gn_stats(s, in, sizeof(TI) == 2, gn_stats, gn_ws, B, HW, n.c, 1e-6f, gn_coef, n.g, n.b);
     gn_part_of = nullptr;
-    launch_gn_apply<float, T>(s, in, gn_coef, out, B, HW, n.c, swish);
+    launch_gn_apply<TI, T>(s, in, gn_coef, out, B, HW, n.c, swish);
 }
 template <typename T>
 void pg_engine::conv3(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual,
-                      int res_f32, int B, int Hi, int Wi, int up, int stride2) {
+                      int res_f32, int B, int Hi, int Wi, int up, int stride2, int feeds_gn) {
     GemmA a; a.kind = stride2 ? 2 : 1; a.ptr = in; a.Hi = Hi; a.Wi = Wi; a.Cin = cw.cin; a.up = up; a.zeros = zeros;
     const int Ho = stride2 ? Hi / 2 : (Hi << up), Wo = stride2 ? Wi / 2 : (Wi << up);
     GemmEpi e; e.out = out; e.out_f32 = out_f32; e.ldc = cw.cout; e.bias_n = cw.b; e.residual = residual; e.res_f32 = res_f32;
     int nsp = 0;
     gn_part_of = nullptr;
-    if (out_f32 && gn_fuse && (Ho / 8) * (Wo / 32) <= 1024) { a.gn_part = gn_ws; a.gn_nsplit = &nsp; }
+    if (feeds_gn < 0) feeds_gn = out_f32;                     // fp32 outputs are the skip stream / GroupNorm inputs
+    if (feeds_gn && gn_fuse && (Ho / 8) * (Wo / 32) <= 1024) { a.gn_part = gn_ws; a.gn_nsplit = &nsp; }
     launch_gemm<T>(s, a, (const T*)cw.w, 9L * cw.cin, 0, e, B * Ho * Wo, cw.cout, 9 * cw.cin, 1);
     if (nsp > 0) { gn_part_of = out; gn_part_n = nsp; gn_part_b = B; }
 }
@@ -1171,8 +1172,15 @@ void pg_engine::resblock(hipStream_t s, const ResBlockW& r, int B, int Hs, int W
         res = t3;
     }
     gn<T>(s, r.n1, (const float*)cur, (T*)t1, B, HW, 1);
-    conv3<T>(s, r.c1, (const T*)t1, t2, 1, nullptr, 0, B, Hs, Ws, 0, 0);
-    gn<T>(s, r.n2, (const float*)t2, (T*)t1, B, HW, 1);
+    // conv1's output only feeds norm2 (not the skip stream): kept in T when mid_bf16 (its GroupNorm statistics still come from
+    // the fp32 accumulators in the epilogue) -- 4 bytes per element less traffic on an HBM-bound pair of kernels
+    if (mid_bf16 && sizeof(T) == 2) {
+        conv3<T>(s, r.c1, (const T*)t1, t2, 0, nullptr, 0, B, Hs, Ws, 0, 0, 1);
+        gn<T, T>(s, r.n2, (const T*)t2, (T*)t1, B, HW, 1);
+    } else {
+        conv3<T>(s, r.c1, (const T*)t1, t2, 1, nullptr, 0, B, Hs, Ws, 0, 0);
+        gn<T>(s, r.n2, (const float*)t2, (T*)t1, B, HW, 1);
+    }
     conv3<T>(s, r.c2, (const T*)t1, t2, 1, res, 1, B, Hs, Ws, 0, 0);
     std::swap(cur, t2);
 }
@@ -1524,6 +1532,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
         return PG_OK;
     }
     if (!strcmp(key, "gn_fuse")) { h->gn_fuse = value != 0; return PG_OK; }
+    if (!strcmp(key, "vq_mid_bf16")) { h->mid_bf16 = value != 0; return PG_OK; }
     if (!strcmp(key, "attn_waves")) { h->tune.attn_waves = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->tune_epoch++; return PG_OK; }
