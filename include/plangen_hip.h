@@ -198,6 +198,7 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *   cu_split (0)        with lanes=2: complementary CU masks on the lane streams (1-4: mask patterns)
  *   lpt_order (1)       longest rows first in the decode-attention launch
  *   attn_variant, attn_waves (0; 4 pins 4-wave blocks)   decode-attention kernel variants
+ *   prefill_attn (2)    MFMA prefill attention: 2 = 128 queries per block, K/V by LDS-DMA, V through the LDS transpose read; 1 = 64-query kernel
  *   gemm256 (1)         256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)
  *   conv_halo (1)       direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: off)
  *   gn_fuse (1)         GroupNorm statistics from the producing convolution's epilogue (halo-tile convolutions)

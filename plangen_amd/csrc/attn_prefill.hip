@@ -10,6 +10,7 @@
 // C layout (row = query 4*g+r), so the per-query rescale factors are fetched with 4 shuffles.
 // K/V come from the KV cache [row][head][slot][128] that rope_kv_kernel just filled.
 #include "kernels.h"
+#include "gemm_common.h"
 
 #define FA_KROW 272          // bytes per K row in LDS (256 + 16 pad)
 #define FA_VROW 144          // bytes per V^T row in LDS (64 keys * 2 + 16 pad)
@@ -146,9 +147,192 @@ __global__ __launch_bounds__(256) void attn_prefill_flash_kernel(const bf16* __r
     }
 }
 
+// ---- v2: 128 queries per block, K/V tiles by LDS-DMA (double-buffered), V consumed through the LDS transpose read -----------------
+// The first kernel spends most of a tile on staging (V transposed with eight 2-byte LDS writes per 16-byte load, two block
+// barriers, 32 MFMAs per wave per 64-key tile).  Here:
+//   * a wave owns 32 queries (two 16-query groups): 64 MFMAs per wave per tile on the same K / V fragments;
+//   * K [64][128] and V [64][128] tiles go global -> LDS by global_load_lds straight from the KV cache (key-major rows of 256 B,
+//     no transpose pass), the NEXT tile in flight while this one is consumed (vmcnt(0) + ONE raw s_barrier per tile);
+//   * 16-byte chunk c of row r sits in slot c ^ (r & 15) for K (conflict-free ds_read_b128 fragments) and c ^ ((r & 3) << 1) for V,
+//     applied through the DMA's source address (the DMA writes lane-linear);
+//   * the PV MFMA's B operand (8 keys of one d column per lane) comes from ds_read_b64_tr_b16: a 16-lane group fetches a
+//     [4 keys][16 d] block (lane i: row i >> 2, four d at (i & 3) * 4) and lane j receives column j -- the V swizzle puts the four
+//     rows of a block in four different 32-byte bank segments;
+//   * query tiles are launched longest first (causal: tile qt reads 2 qt + 2 key tiles); a wave skips key tiles that lie entirely
+//     in its queries' future.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+#define FB_TILE 16384
+__device__ __forceinline__ u32x2 lds_tr16(const char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(u32x2, v);
+}
+__global__ __launch_bounds__(256, 2) void attn_prefill_flash2_kernel(const bf16* __restrict__ qbuf, bf16* __restrict__ obuf,
+                                                                    const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+                                                                    const int32_t* __restrict__ row_off, const int32_t* __restrict__ len,
+                                                                    int nh, int slots, float scale, int nqt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];                    // K[2][16 KiB] | V[2][16 KiB]
+    const int qt = nqt - 1 - (int)blockIdx.x, head = blockIdx.y, row = blockIdx.z;
+    const int off = row_off[row];
+    const int L = len[row];
+    if (off < 0 || qt * 128 >= L) return;
+    const int tid = threadIdx.x, l = tid & 63, g = l >> 4, lr = l & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HD = nh * 128;
+    const int q0w = qt * 128 + w * 32;                                              // first query of this wave
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+        const int myq = q0w + qg * 16 + lr;
+        const int qq = myq < L ? myq : L - 1;
+        const bf16* qp = qbuf + (long)(off + qq) * HD + head * 128 + g * 8;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const u32x4 v = *(const u32x4*)(qp + ds * 32);
+            float f[8]; ET<bf16>::unpack(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= scale;
+            const u32x4 pv = ET<bf16>::pack(f);
+            qf[qg][ds] = *(const bf16x8*)&pv;
+        }
+    }
+    const bf16* kbase = kc + ((long)row * nh + head) * slots * 128;
+    const bf16* vbase = vc + ((long)row * nh + head) * slots * 128;
+    // DMA: wave w, instruction i covers tile rows (w*4 + i)*4 .. +3 (lane: row l >> 4, slot l & 15)
+    int rr[4], ksw[4], vsw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (w * 4 + i) * 4 + (l >> 4);
+        rr[i] = r; ksw[i] = ((l & 15) ^ (r & 15)) * 8; vsw[i] = ((l & 15) ^ ((r & 3) << 1)) * 8;
+    }
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        const int kb = t * 64;
+        char* kd = smem + (t & 1) * FB_TILE + w * 4096;
+        char* vd = kd + 2 * FB_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int key = kb + rr[i];
+            key = key < L ? key : L - 1;
+            glds16(kbase + (long)key * 128 + ksw[i], kd + i * 1024);
+            glds16(vbase + (long)key * 128 + vsw[i], vd + i * 1024);
+        }
+    };
+    f32x4 oacc[2][8];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) oacc[qg][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const int qlast = min(qt * 128 + 127, L - 1);
+    const int ntiles = qlast / 64 + 1;                                             // causal: keys 0 .. qlast
+    // V transpose-read addressing: rows key0 + (lr >> 2), logical chunk 2 dt + ((lr & 3) >> 1), 8-byte half lr & 1
+    const int vlane = (4 * g + (lr >> 2)) * 256 + (lr & 1) * 8;
+    const int vcb = (lr & 3) >> 1, vsz = (lr >> 2) << 1;
+    issue(0);
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // this wave's pieces of tile t have landed
+        __builtin_amdgcn_s_barrier();                                               // ... everyone's; and everyone is done with tile t-1
+        if (t + 1 < ntiles) issue(t + 1);
+        const int kb = t * 64;
+        if (kb > q0w + 31) continue;                                                // the whole tile is in the future of this wave's queries
+        const char* sK = smem + (t & 1) * FB_TILE;
+        const char* sV = sK + 2 * FB_TILE;
+        f32x4 sacc[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            sacc[0][kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; sacc[1][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) {
+                const bf16x8 ka = *(const bf16x8*)(sK + (kt * 16 + lr) * 256 + (((ds * 4 + g) ^ lr) << 4));
+                sacc[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[0][ds], sacc[0][kt], 0, 0, 0);
+                sacc[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[1][ds], sacc[1][kt], 0, 0, 0);
+            }
+        }
+        const bool need_mask = (kb + 63 > q0w) || (kb + 64 > L);
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) {
+            const int myq = q0w + qg * 16 + lr;
+            float mx = m_run[qg];
+            if (need_mask) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kb + kt * 16 + g * 4 + r;
+                        if (key > myq || key >= L) sacc[qg][kt][r] = -INFINITY;
+                    }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[qg][kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float alpha = __expf(m_run[qg] - mx);                              // key 0 is visible to every query: mx finite from tile 0
+            float psum = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float p[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __expf(sacc[qg][2 * s2][r] - mx);
+                    p[4 + r] = __expf(sacc[qg][2 * s2 + 1][r] - mx);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) psum += p[e];
+                const u32x4 pv = ET<bf16>::pack(p);
+                pf[qg][s2] = *(const bf16x8*)&pv;
+            }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run[qg] = l_run[qg] * alpha + psum;
+            m_run[qg] = mx;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) oacc[qg][dt][r] *= a;
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const int co = ((2 * dt + vcb) ^ vsz) << 4;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* va = sV + (32 * s2) * 256 + vlane + co;
+                const u32x2 lo = lds_tr16(va), hi = lds_tr16(va + 16 * 256);
+                u32x4 vb; vb.x = lo.x; vb.y = lo.y; vb.z = hi.x; vb.w = hi.y;
+                const bf16x8 vf = *(const bf16x8*)&vb;
+                oacc[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[0][s2], vf, oacc[0][dt], 0, 0, 0);
+                oacc[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[1][s2], vf, oacc[1][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lq = __shfl(l_run[qg], g * 4 + r, 64);
+            const int q = q0w + qg * 16 + g * 4 + r;
+            if (q < L) {
+                const float inv = 1.f / lq;
+                bf16* op = obuf + (long)(off + q) * HD + head * 128 + lr;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) ET<bf16>::st(op + dt * 16, oacc[qg][dt][r] * inv);
+            }
+        }
+}
+
 void launch_attn_prefill_flash(hipStream_t s, const bf16* qbuf, bf16* obuf, const bf16* kc, const bf16* vc,
                                const int32_t* row_off, const int32_t* len, int R, int max_len, int nh, int slots, float scale) {
     if (R <= 0 || max_len <= 0) return;
+    if (pg_tune->prefill_attn != 1) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_prefill_flash2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * FB_TILE); attr = true; }
+        const int nqt = (max_len + 127) / 128;
+        hipLaunchKernelGGL(attn_prefill_flash2_kernel, dim3(nqt, nh, R), dim3(256), 4 * FB_TILE, s, qbuf, obuf, kc, vc, row_off, len, nh, slots, scale, nqt);
+        return;
+    }
     hipLaunchKernelGGL(attn_prefill_flash_kernel, dim3((max_len + 63) / 64, nh, R), dim3(256), 0, s, qbuf, obuf, kc, vc, row_off, len,
                        nh, slots, scale);
 }

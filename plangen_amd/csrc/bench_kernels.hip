@@ -384,3 +384,28 @@ extern "C" int pg_bench_dma_order(int blocks, int iters, int mode, unsigned* fai
     hipFree(cold); hipFree(hot); hipFree(fails); hipFree(sink);
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Semantics probe for ds_read_b64_tr_b16 (gfx950 LDS transpose read): LDS holds lds[i] = i (16-bit); lane l reads at byte address
+// addr[l]; out[l*4 + j] = element j of the returned 64 bits.
+__global__ void tr16_probe_kernel(const int* __restrict__ addr, unsigned short* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 64) lds[i] = (unsigned short)i;
+    __syncthreads();
+    const unsigned a = (unsigned)(size_t)lds + (unsigned)addr[threadIdx.x];
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    out[threadIdx.x * 4 + 0] = (unsigned short)(v.x & 0xffff); out[threadIdx.x * 4 + 1] = (unsigned short)(v.x >> 16);
+    out[threadIdx.x * 4 + 2] = (unsigned short)(v.y & 0xffff); out[threadIdx.x * 4 + 3] = (unsigned short)(v.y >> 16);
+}
+extern "C" int pg_bench_tr16_probe(const int* addr_host, unsigned short* out_host) {
+    int* a; unsigned short* o;
+    hipMalloc((void**)&a, 64 * 4); hipMalloc((void**)&o, 256 * 2);
+    hipMemcpy(a, addr_host, 64 * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(tr16_probe_kernel, dim3(1), dim3(64), 0, 0, a, o);
+    hipDeviceSynchronize();
+    const int rc = hipGetLastError() == hipSuccess ? 0 : -2;
+    hipMemcpy(out_host, o, 256 * 2, hipMemcpyDeviceToHost);
+    hipFree(a); hipFree(o);
+    return rc;
+}
