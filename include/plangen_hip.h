@@ -194,6 +194,8 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *   share_uncond (1)    prefill / store a batch-constant negative prompt once
  *   flash_prefill (1)   MFMA flash attention for prefill (0: per-query streaming kernel)
  *   fuse_rope (1)       RoPE + KV append inside the decode-attention kernel
+ *   skip_attn (0)       MEASUREMENT ONLY: decode steps without their attention launches (results are garbage); bench.py times the
+ *                       graph-replayed GEMM + norm phase with it
  *   lanes (1)           2: two row-range lanes on two streams
  *   cu_split (0)        with lanes=2: complementary CU masks on the lane streams (1-4: mask patterns)
  *   lpt_order (1)       longest rows first in the decode-attention launch

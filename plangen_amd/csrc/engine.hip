@@ -127,6 +127,7 @@ struct pg_engine {
     hipGraphExec_t gexec_txt = nullptr; std::vector<int64_t> gkey_txt;      // text-decode step (lm_head + argmax + stack)
     void drop_graphs() { if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; } if (gexec_txt) { (void)hipGraphExecDestroy(gexec_txt); gexec_txt = nullptr; } }
     bool use_graph = true; bool time_attn = false; bool fuse_rope = true; bool force_swiglu = true; bool gn_fuse = true; bool mid_bf16 = true; int cu_split = 0;
+    bool skip_attn = false;                                      // measurement only: the decode step WITHOUT its attention launches (bench.py's graph-replayed GEMM + norm phase time)
     // per-kernel-class HIP-event timing of the decode loop (eager instrumented pass, pg_set_option("time_attn", 1)):
     // one event pair per launch group on the launch stream, on every ``time_stride``-th decode step
     enum { TC_ATTN = 0, TC_QKV, TC_O, TC_GU, TC_DOWN, TC_NORM, TC_HEAD, TC_SAMPLE, TC_EMPTY, TC_N };
@@ -735,7 +736,9 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         tic(s);
         gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk, ly.wqkv_t);
         toc(s, TC_QKV, 3.0 * HDm * Hh * wb);
-        if (mode == 0 && fuse_rope) {
+        if (mode == 0 && skip_attn) {
+            // nothing: the GEMM + norm phase alone (outputs are garbage by construction)
+        } else if (mode == 0 && fuse_rope) {
             tic(s);
             launch_attn_decode_fused<T>(s, part, S_last, slab_last, (T*)obuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), M,
                                         cfg.n_heads, slots, max_pos, scale);
@@ -754,7 +757,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
             if (!done)
                 launch_attn<T>(s, (const T*)qbuf, (T*)obuf, (const T*)kc(li), (const T*)vc(li), seq(), mode, M, cfg.n_heads, slots, scale);
         }
-        if (tc_on) {
+        if (tc_on && !(mode == 0 && skip_attn)) {
             double keys = shared_len;       // the shared uncond prompt is read from HBM once per launch
             for (int r = 0; r < R; ++r) keys += (double)(h_len[h_len_off + r] + n_dec_host + 1) - ((shared_len > 0 && (r & 1)) ? shared_len : 0);
             toc(s, TC_ATTN, keys * cfg.n_heads * 128 * 2 * (double)esz);
@@ -993,7 +996,7 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
         // shapes and kernel selection only: seeds, temperatures, T and the caller's buffers reach the kernels through
         // device memory, so a bench / serving loop replays ONE instantiated graph across calls
         std::vector<int64_t> key = {Rtot, (int64_t)bf, (int64_t)logits_out, (int64_t)shared_len, (int64_t)fuse_rope, (int64_t)nl,
-                                    (int64_t)(lpt_order && order_valid), (int64_t)tune_epoch};
+                                    (int64_t)(lpt_order && order_valid), (int64_t)tune_epoch, (int64_t)skip_attn};
         if (!gexec || key != gkey) {
             if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
             hipGraph_t g = nullptr;
@@ -1489,6 +1492,7 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
 int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!h || !key) return PG_ERR_ARG;
     if (!strcmp(key, "time_attn")) { h->time_attn = value != 0; return PG_OK; }
+    if (!strcmp(key, "skip_attn")) { h->skip_attn = value != 0; return PG_OK; }
     if (!strcmp(key, "rng_image_offset")) { h->rng_image_offset = (int)value; return PG_OK; }
     if (!strcmp(key, "time_stride")) { h->time_stride = value > 0 ? (int)value : 1; return PG_OK; }
     if (!strcmp(key, "allow_partial_weights")) { h->allow_partial = value != 0; return PG_OK; }
