@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qbuf, T
 // K/V chunk of every wave is issued BEFORE the prologue's dependent chain (slab loads -> RoPE -> LDS -> barrier) and consumed right
 // after the barrier, in the loop's own kv[] / vv[] registers (no double buffer, still 4 waves per SIMD); the append is ONE
 // 8-byte-per-lane store instruction per block, issued after the barrier.  Loop 1800 -> 1783 ms at bs=64.
-template <typename T, int UN, int NW>
+template <typename T, int UN, int NW, int ABL = 0>      // ABL (timing ablations, WRONG results): 1 no K/V append store, 2 no slab / cos / sin loads, 4 no merge epilogue
 __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float* __restrict__ qkv, int S, long slab,
                                                               T* __restrict__ obuf, T* __restrict__ kc, T* __restrict__ vc,
                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
@@ -321,12 +321,14 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
         for (int u = 0; u < UN; ++u) {
             int key = base + u * KPI + grp;
             key = key < k1 ? key : k1 - 1;
+            key = key < 0 ? 0 : key;                                 // k1 == 0 (peeled issue of an empty segment): slot 0 is always mapped
             kv[u] = NTL ? __builtin_nontemporal_load((const u32x4*)(kb + (long)key * 128)) : *(const u32x4*)(kb + (long)key * 128);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             int key = base + u * KPI + grp;
             key = key < k1 ? key : k1 - 1;
+            key = key < 0 ? 0 : key;
             vv[u] = NTL ? __builtin_nontemporal_load((const u32x4*)(vb + (long)key * 128)) : *(const u32x4*)(vb + (long)key * 128);
         }
     };
@@ -343,6 +345,13 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
     if (pos >= max_pos) pos = max_pos - 1;
     const float* const qrow = qkv + (long)row * 3 * HD + head * 128 + (tid & 63);
     if (tid < 64) {
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 6; ++v) t4[u][v] = 0.01f * (float)(tid + v);
+            cs = 1.f; sn = 0.f;
+        } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float* qq = qrow + (long)(u < S ? u : S - 1) * slab;
@@ -350,9 +359,13 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
             for (int v = 0; v < 6; ++v) t4[u][v] = qq[o6[v]];
         }
         cs = cos_t[(long)pos * 64 + tid]; sn = sin_t[(long)pos * 64 + tid];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);          // the slab sums must not be scheduled (with their vmcnt waits) in front of the K/V issue
-    if (have0) { if (sh) issue(kshr, vshr, base0, seg_k1, std::false_type{}); else issue(kpriv, vpriv, base0, seg_k1, std::true_type{}); }
+    // UNCONDITIONAL (addresses clamped into the segment): behind a branch the compiler must count wave 0's slab waits for the path
+    // that issued nothing, i.e. 14 ops too strict on the path that did -- the RoPE prologue then waited for 12 of the 14 K/V loads
+    // (3.5 us per launch in the in-loop ablation)
+    if (sh) issue(kshr, vshr, base0, seg_k1, std::false_type{}); else issue(kpriv, vpriv, base0, seg_k1, std::true_type{});
     __builtin_amdgcn_sched_barrier(0);
 
     if (tid < 64) {
@@ -383,18 +396,6 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
         float d = s_q[l] * s_k[l] + s_q[l + 64] * s_k[l + 64];
         d = wave_sum(d);
         if (l == 0) s_new = d;
-        // K/V append: ONE store instruction per block (lanes 0-31 the K row, 32-63 the V row, 4 elements each) instead of four
-        // 2-byte-per-lane stores before the barrier (in-loop ablation: the narrow stores cost 2.4 us per launch)
-        if (slot < slots) {
-            const float* src = (l < 32 ? s_k : s_v) + (l & 31) * 4;
-            T* dst = (l < 32 ? kc : vc) + cbase + (long)slot * 128 + (l & 31) * 4;
-            if constexpr (sizeof(T) == 2) {
-                u32x2 pk; pk.x = pack_bf16x2(src[0], src[1]); pk.y = pack_bf16x2(src[2], src[3]);
-                *(u32x2*)dst = pk;
-            } else {
-                *(f32x4*)dst = *(const f32x4*)src;
-            }
-        }
     }
     float q[EPV];
 #pragma unroll
@@ -443,6 +444,13 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
     } else {
         run(kpriv, vpriv, base0 + NW * KPW, nprev, std::true_type{});
     }
+    if constexpr (ABL & 4) {
+        float acc = l_run + m_run;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc += o[e];
+        if (acc == 123.456f) ET<T>::st(obuf + (long)row * HD + head * 128 + tid % 128, acc);
+        return;
+    }
     const int stt = w * KPI + grp;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) s_o[stt][lk * EPV + e] = o[e];
@@ -462,6 +470,19 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
         }
         ET<T>::st(obuf + (long)row * HD + head * 128 + tid, num / den);
     }
+    // K/V append, LAST thing the block does: ONE store instruction (lanes 0-31 the K row, 32-63 the V row, 4 elements each) from the
+    // RoPE'd row still sitting in LDS.  Nothing waits behind it: issued right after the prologue it sat in front of wave 0's first
+    // `vmcnt` wait (counted in order), and the store's acknowledgement cost 2.4 us of every launch (in-loop ablation, 34 ms per loop).
+    if (!(ABL & 1) && tid < 64 && slot < slots) {
+        const float* src = (l < 32 ? s_k : s_v) + (l & 31) * 4;
+        T* dst = (l < 32 ? kc : vc) + cbase + (long)slot * 128 + (l & 31) * 4;
+        if constexpr (sizeof(T) == 2) {
+            u32x2 pk; pk.x = pack_bf16x2(src[0], src[1]); pk.y = pack_bf16x2(src[2], src[3]);
+            *(u32x2*)dst = pk;
+        } else {
+            *(f32x4*)dst = *(const f32x4*)src;
+        }
+    }
 }
 template <typename T>
 void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc,
@@ -472,7 +493,11 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
     if ((M * nh <= 512 && pg_tune->attn_waves != 4) || pg_tune->attn_waves == 8)
         hipLaunchKernelGGL((attn_decode_fused_kernel<T, 7, 8>), dim3(nh, M), dim3(512), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
                            st, nh, slots, max_pos, scale);
-    else
+    else if (pg_tune->attn_variant >= 100 && pg_tune->attn_variant < 108) {      // timing ablations (results wrong by construction)
+#define ATT_ABL(A) case 100 + A: hipLaunchKernelGGL((attn_decode_fused_kernel<T, 7, 4, A>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, nh, slots, max_pos, scale); break;
+        switch (pg_tune->attn_variant) { ATT_ABL(1) ATT_ABL(2) ATT_ABL(3) ATT_ABL(4) ATT_ABL(7) default: break; }
+#undef ATT_ABL
+    } else
         hipLaunchKernelGGL((attn_decode_fused_kernel<T, 7, 4>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
                            st, nh, slots, max_pos, scale);
 }
