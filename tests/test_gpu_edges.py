@@ -246,3 +246,29 @@ def test_two_handles_keep_their_own_tuning(tiny_cfg, tiny_weights):
     assert S_b > S_a
     assert a.op_gemm_splits(x, w) == S_a
     b.close()
+
+
+def test_bench_line_contract_tiny():
+    """`bench.py` prints ONE JSON line with the driver's keys, the dominant-kernel roofline (HIP-event timed), the per-class
+    table and the graph-replayed GEMM + norm phase (tiny config, a few seconds)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tiny", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert "workload" in j["config"] and j["value"] > 0
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "decode_attention" in r["classes"] and "decode_gemm_qkv" in r["classes"]
+    ph = r["decode_gemm_norm_phase"]
+    assert ph["ms_per_step"] > 0 and ph["events_ms_per_step"] > 0 and "method" in ph
