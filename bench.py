@@ -41,13 +41,14 @@ def synth_prompts(B, L, vocab, pad_id, seed):
     import torch
     g = torch.Generator().manual_seed(seed)
     lo, unc = max(1, (L * 160) // 256), max(1, (L * 96) // 256)
+    hi = vocab - 2048 if vocab > 4096 else vocab               # full vocabulary: stay below the special-token tail
     ids = torch.full((2 * B, L), pad_id, dtype=torch.int32)
     mask = torch.zeros((2 * B, L), dtype=torch.int32)
-    unc_ids = torch.randint(10, vocab - 2048, (unc,), generator=g).int()
+    unc_ids = torch.randint(10, hi, (unc,), generator=g).int()
     unc_ids[0] = 1
     for b in range(B):
         n = int(torch.randint(lo, L + 1, (1,), generator=g))
-        row = torch.randint(10, vocab - 2048, (n,), generator=g).int()
+        row = torch.randint(10, hi, (n,), generator=g).int()
         row[0] = 1
         ids[2 * b, L - n:] = row
         mask[2 * b, L - n:] = 1
