@@ -134,28 +134,45 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
         const int i = tid * 4 + j * 1024;
         if (xn && i < H) { if constexpr (sizeof(T) == 2) wv2[j] = *(const u32x2*)(w + i); else wv4[j] = *(const f32x4*)(w + i); }
     }
+    // ALL of the row's loads go out before the first add: x and the first four slabs of every one of the thread's NV vectors in one
+    // straight-line batch (a plain ``for s`` loop is not unrolled by hipcc for runtime S and degenerates into S dependent round trips;
+    // and with the batch inside the per-vector loop the second vector's loads waited for the first vector's adds: two round trips
+    // per row at NV = 2, 5.2 us per launch)
+    constexpr int SB = 4;
+    f32x4 t[NV][SB];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i = tid * 4 + j * 1024;
-        v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ic = i < H ? i : 0;                                  // clamped: loads unconditional, results discarded
+        v[j] = *(const f32x4*)(xr + ic);
+        // branch-free: S == 0 (no slabs, ``partial`` may be null) reads the residual row again and discards it; a conditional load
+        // makes hipcc drain vmcnt at every join
+        const float* pp = (S > 0 ? partial + (long)m * H : xr) + ic;
+        const long sl = S > 0 ? slab : 0;
+        const int smax = S > 0 ? S - 1 : 0;
+#pragma unroll
+        for (int u = 0; u < SB; ++u) t[j][u] = *(const f32x4*)(pp + (long)(u < smax ? u : smax) * sl);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid * 4 + j * 1024;
         if (i < H) {
-            v[j] = *(const f32x4*)(xr + i);
-            // slab loads in batches of 8 independent requests (a plain ``for s`` loop is not unrolled
-            // by hipcc for runtime S and degenerates into S dependent round trips)
+#pragma unroll
+            for (int u = 0; u < SB; ++u) if (u < S) v[j] += t[j][u];
             const float* pp = partial + (long)m * H + i;
-            for (int s0 = 0; s0 < S; s0 += 8) {
-                f32x4 t[8];
+            for (int s0 = SB; s0 < S; s0 += 8) {                       // S > 4: further batches of 8 independent requests
+                f32x4 t8[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int s = s0 + u < S ? s0 + u : S - 1;
-                    t[u] = *(const f32x4*)(pp + (long)s * slab);
+                    const int sidx = s0 + u < S ? s0 + u : S - 1;
+                    t8[u] = *(const f32x4*)(pp + (long)sidx * slab);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (s0 + u < S) v[j] += t[u];
+                for (int u = 0; u < 8; ++u) if (s0 + u < S) v[j] += t8[u];
             }
             if (S > 0) *(f32x4*)(xr + i) = v[j];
             ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-        }
+        } else v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     ss = block_sum<4>(ss, red);
     if (!xn) return;
