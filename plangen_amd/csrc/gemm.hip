@@ -452,15 +452,24 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
         for (int j = 0; j < XV; ++j) {
             const int v = tid + j * NTH, row = v >> 4, cv = v & 15;
             const int m = mbase + row;
-            if (row < MT * 16 && m < M) xs[j] = *(const u32x4*)(xp + (long)m * K + c * SK_BK + cv * 8);
-            else xs[j] = (u32x4){0u, 0u, 0u, 0u};
+            // BRANCH-FREE (row clamped into the matrix; rows >= M are never stored): behind `if (m < M)` hipcc put every x load
+            // in its own exec-masked block with `s_waitcnt vmcnt(0)` at the joins -- four serialised memory round trips (and a drain
+            // of the W ring's first loads) before the first MFMA
+            if constexpr ((MT * 256) % NTH == 0) {
+                xs[j] = *(const u32x4*)(xp + (long)(m < M ? m : M - 1) * K + c * SK_BK + cv * 8);
+            } else {
+                if (row < MT * 16) xs[j] = *(const u32x4*)(xp + (long)(m < M ? m : M - 1) * K + c * SK_BK + cv * 8);
+                else xs[j] = (u32x4){0u, 0u, 0u, 0u};
+            }
         }
     };
     auto xstore = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < XV; ++j) {
             const int v = tid + j * NTH, row = v >> 4, cv = v & 15;
-            if (row < MT * 16) *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
+            // unconditional when the tile divides over the block (hipcc cannot prove tid < NTH, keeps the guard, and SINKS the matching
+            // x load into it: a conditional load with a `vmcnt(0)` at the join)
+            if ((MT * 256) % NTH == 0 || row < MT * 16) *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
         }
     };
     bf16x8 wr[D][4];
