@@ -668,13 +668,34 @@ __global__ __launch_bounds__(256) void text_scan_kernel(TextArgs a, float* __res
     const float* lp = a.logits_partial + (long)b * a.V;
     float best = -INFINITY; int bi = 0x7fffffff;
     if (((a.V | (int)(a.slab & 3)) & 3) == 0) {
-        for (int v = v0 + tid * 4; v < v1; v += 1024) {
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < a.S; ++s) c += *(const f32x4*)(lp + (long)s * a.slab + v);
+        // eight independent 16-byte loads per slab in flight per thread (addresses clamped into the chunk, validity applied to the
+        // compare): a plain `for v` / `for s` nest is one dependent round trip per vector and slab
+        constexpr int IT = 8;
+        for (int vb = v0 + tid * 4; vb < v1; vb += IT * 1024) {
+            f32x4 c[IT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float cj = (v + j == ban) ? -INFINITY : c[j];
-                if (cj > best) { best = cj; bi = v + j; }
+            for (int it = 0; it < IT; ++it) {
+                const int v = vb + it * 1024;
+                c[it] = *(const f32x4*)(lp + (v < v1 ? v : v1 - 4));
+            }
+            for (int s = 1; s < a.S; ++s) {
+                f32x4 t[IT];
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int v = vb + it * 1024;
+                    t[it] = *(const f32x4*)(lp + (long)s * a.slab + (v < v1 ? v : v1 - 4));
+                }
+#pragma unroll
+                for (int it = 0; it < IT; ++it) c[it] += t[it];
+            }
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int v = vb + it * 1024;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float cj = (v + j == ban || v >= v1) ? -INFINITY : c[it][j];
+                    if (cj > best) { best = cj; bi = v + j; }
+                }
             }
         }
     } else {
