@@ -590,19 +590,52 @@ __global__ __launch_bounds__(256) void cfg_scan_kernel(SampleArgs a, float* __re
     const float temperature = a.p->temperature, cfg_weight = a.p->cfg_weight;
     const uint64_t seed = a.p->seed;
     const float invT = temperature > 0.f ? 1.f / temperature : 1.f;
-    for (int v = v0 + tid; v < v1; v += 256) {
-        const float b0 = a.bias ? a.bias[v] : 0.f;
-        float cu[2] = {b0, b0};
-        const int ocu[2] = {0, a.V};                          // cond row, uncond row (adjacent rows)
-        sum_slabs<2>(a.logits_partial + rc + v, a.slab, a.S, ocu, cu);
-        const float c = cu[0], u = cu[1];
-        float mixed = u + cfg_weight * (c - u);
-        if (a.logits_out) a.logits_out[((long)step * B + bg) * a.V + v] = mixed;
-        if (temperature > 0.f) {
-            const float uu = rng_uniform(seed, (uint64_t)(bg + a.p->img_off) * 1000003ull + step, v);
-            mixed = mixed * invT - __logf(-__logf(uu));
+    // four vocabulary entries per thread per pass, ALL their loads (bias, cond / uncond row of every slab) issued before the first use
+    // (indices clamped into the chunk): one memory round trip per pass instead of one per entry
+    constexpr int IT = 4;
+    const float* bias0 = a.bias ? a.bias : a.logits_partial + rc;     // no bias: any mapped address, value discarded
+    const int ocu[2] = {0, a.V};                                      // cond row, uncond row (adjacent rows)
+    for (int vb = v0 + tid; vb < v1; vb += IT * 256) {
+        float bb[IT], cu[IT][2];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = vb + it * 256, vc = v < v1 ? v : v1 - 1;
+            bb[it] = bias0[vc];
         }
-        if (mixed > best) { best = mixed; bi = v; }
+        float t[IT][4][2];
+        const int smax = a.S > 0 ? a.S - 1 : 0;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = vb + it * 256, vc = v < v1 ? v : v1 - 1;
+            const float* pp = a.logits_partial + rc + vc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* q = pp + (long)(u < smax ? u : smax) * a.slab;       // slab index clamped: branch-free loads
+                t[it][u][0] = q[0]; t[it][u][1] = q[a.V];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = vb + it * 256, vc = v < v1 ? v : v1 - 1;
+            cu[it][0] = a.bias ? bb[it] : 0.f; cu[it][1] = cu[it][0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (u < a.S) { cu[it][0] += t[it][u][0]; cu[it][1] += t[it][u][1]; }
+            if (a.S > 4) sum_slabs<2>(a.logits_partial + rc + vc + 4 * a.slab, a.slab, a.S - 4, ocu, cu[it]);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = vb + it * 256;
+            if (v < v1) {
+                const float c = cu[it][0], u = cu[it][1];
+                float mixed = u + cfg_weight * (c - u);
+                if (a.logits_out) a.logits_out[((long)step * B + bg) * a.V + v] = mixed;
+                if (temperature > 0.f) {
+                    const float uu = rng_uniform(seed, (uint64_t)(bg + a.p->img_off) * 1000003ull + step, v);
+                    mixed = mixed * invT - __logf(-__logf(uu));
+                }
+                if (mixed > best) { best = mixed; bi = v; }
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
