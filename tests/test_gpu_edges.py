@@ -272,3 +272,29 @@ def test_bench_line_contract_tiny():
     assert "decode_attention" in r["classes"] and "decode_gemm_qkv" in r["classes"]
     ph = r["decode_gemm_norm_phase"]
     assert ph["ms_per_step"] > 0 and ph["events_ms_per_step"] > 0 and "method" in ph
+
+
+def test_bf16_flash_prefill_at_tile_boundaries(tiny_cfg, tiny_weights):
+    """Both MFMA prefill-attention kernels (128-query LDS-DMA / transpose-read and 64-query) on prompt lengths that straddle their
+    64-key and 64 / 128-query tiles (1, 2, 63, 64, 65, 127, 128, 129, 257 real tokens, left-padded): per-position hidden states agree
+    with the fp32 engine within the bf16 bound and with each other."""
+    L = 288
+    lens = [1, 2, 63, 64, 65, 127, 129, 257]
+    eb = get_engine(tiny_cfg, tiny_weights, "bf16", max_prompt=L)
+    ef = get_engine(tiny_cfg, tiny_weights, "f32", max_prompt=L)
+    g = torch.Generator().manual_seed(77)
+    ids = torch.randint(8, tiny_cfg.vocab, (len(lens), L), generator=g).int()
+    pad = [L - n for n in lens]
+    ref = ef.prefill(ids, pad, position_mode=0, return_hidden=True).float().cpu()
+    outs = {}
+    for variant in (2, 1):
+        eb.set_option("prefill_attn", variant)
+        outs[variant] = eb.prefill(ids, pad, position_mode=0, return_hidden=True).float().cpu()
+    eb.set_option("prefill_attn", 2)
+    scale = ref.abs().max().item()
+    for r, n in enumerate(lens):
+        for variant in (2, 1):
+            err = (outs[variant][r, L - n:] - ref[r, L - n:]).abs().max().item()
+            assert err < 0.05 * scale, (variant, n, err, scale)
+            assert outs[variant][r, :L - n].abs().max().item() == 0.0 if n < L else True
+    assert (outs[2] - outs[1]).abs().max().item() < 0.03 * scale
