@@ -119,7 +119,7 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t a, uint64_t
 
 // One row of (split-K reduce + residual add + RMSNorm) by a 256-thread block (rmsnorm_kernel and the
 // norm blocks of the fused norm+GEMM launch share it).  ``red``: >= 4 floats of LDS.
-template <typename T, int NV, bool SC1 = false>
+template <typename T, int NV, bool SC1 = false, int SB = 4>      // SB: slabs loaded in the up-front batch (4, or 8 for S > 4)
 __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const float* __restrict__ partial,
                                             int S, long slab, const T* __restrict__ w,
                                             T* __restrict__ xn, int H, float eps, float* red) {
@@ -138,7 +138,6 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
     // straight-line batch (a plain ``for s`` loop is not unrolled by hipcc for runtime S and degenerates into S dependent round trips;
     // and with the batch inside the per-vector loop the second vector's loads waited for the first vector's adds: two round trips
     // per row at NV = 2, 5.2 us per launch)
-    constexpr int SB = 4;
     f32x4 t[NV][SB];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -160,7 +159,7 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
 #pragma unroll
             for (int u = 0; u < SB; ++u) if (u < S) v[j] += t[j][u];
             const float* pp = partial + (long)m * H + i;
-            for (int s0 = SB; s0 < S; s0 += 8) {                       // S > 4: further batches of 8 independent requests
+            for (int s0 = SB; s0 < S; s0 += 8) {                       // S > SB: further batches of 8 independent requests
                 f32x4 t8[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {

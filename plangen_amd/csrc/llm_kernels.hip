@@ -34,12 +34,12 @@ __device__ __forceinline__ void sum_slabs(const float* __restrict__ p, long slab
 // Register-resident fast path: H <= NV*1024, thread holds NV float4 (no LDS row buffer), all
 // (S+1)*NV loads are independent and issued up front, weights / outputs moved as 8- or 16-byte
 // vectors.
-template <typename T, int NV>
+template <typename T, int NV, int SB = 4>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, const float* __restrict__ partial,
                                                      int S, long slab, const T* __restrict__ w,
                                                      T* __restrict__ xn, int H, float eps, int32_t* __restrict__ advance) {
     __shared__ float red[4];
-    rmsnorm_row<T, NV>(blockIdx.x, x, partial, S, slab, w, xn, H, eps, red);
+    rmsnorm_row<T, NV, false, SB>(blockIdx.x, x, partial, S, slab, w, xn, H, eps, red);
     // the decode step's LAST kernel also advances the device step counter (no kernel of the step reads it after this
     // point; saves the 1-thread advance launch of every step)
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
@@ -49,6 +49,7 @@ void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long s
                     int M, int H, float eps, int32_t* advance) {
     if (M <= 0) return;
     if (H <= 1024) hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
+    else if (H <= 2048 && S > 4) hipLaunchKernelGGL((rmsnorm_kernel<T, 2, 8>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);   // 5-8 slabs (small row counts): still one round trip
     else if (H <= 2048) hipLaunchKernelGGL((rmsnorm_kernel<T, 2>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
     else if (H <= 4096) hipLaunchKernelGGL((rmsnorm_kernel<T, 4>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
     else hipLaunchKernelGGL((rmsnorm_kernel<T, 8>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
