@@ -201,6 +201,7 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *   lpt_order (1)       longest rows first in the decode-attention launch
  *   attn_variant, attn_waves (0; 4 pins 4-wave blocks)   decode-attention kernel variants
  *   prefill_attn (2)    MFMA prefill attention: 2 = 128 queries per block, K/V by LDS-DMA, V through the LDS transpose read; 1 = 64-query kernel
+ *   ln_wave (1)         SigLIP LayerNorm (width 1024): wave-per-row register kernel; 0 = block-per-row kernel
  *   gemm256 (1)         256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)
  *   conv_halo (1)       direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: off)
  *   gn_fuse (1)         GroupNorm statistics from the producing convolution's epilogue (halo-tile convolutions)

@@ -1542,6 +1542,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "attn_variant")) { h->tune.attn_variant = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "prefill_attn")) { h->tune.prefill_attn = (int)value; h->tune_epoch++; return PG_OK; }
+    if (!strcmp(key, "ln_wave")) { h->tune.ln_wave = (int)value; return PG_OK; }
     h->err = std::string("unknown option ") + key;
     return PG_ERR_ARG;
 }

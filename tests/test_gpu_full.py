@@ -184,6 +184,10 @@ def test_mmu_and_uni_2stage_full_size_properties():
     assert f3.shape == (3, cfg.vit_tokens, cfg.hidden) and torch.isfinite(f3.float()).all()
     assert torch.equal(f3[:2], f2)                                   # an image's features ignore its batch mates
     assert f3.float().std() > 1e-3
+    e.set_option("ln_wave", 0)                                       # block-per-row LayerNorm instead of the wave-per-row register kernel
+    f3g = e.vision_encode(pix)
+    e.set_option("ln_wave", 1)
+    assert (f3g.float() - f3.float()).abs().max().item() < 0.02 * f3.float().abs().max().item()      # same features up to bf16 rounding of 24 layers
 
     B, P = 2, cfg.vit_tokens
     ids = torch.full((B, L), cfg.pad_id, dtype=torch.int64)
