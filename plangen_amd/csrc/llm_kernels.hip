@@ -435,7 +435,64 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
             m_run = mx;
         }
     };
+    // explicitly software-pipelined form of the loop (ABL bit 16, experiment): K(i+1) goes out BEFORE the wait for V(i), so one of the
+    // two round trips of an iteration runs under the other's arithmetic; loads unconditional (clamped) so the counted waits stay exact
+    auto issueK = [&](const T* kb, int base, int k1) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int key = base + u * KPI + grp;
+            key = key < k1 ? key : k1 - 1;
+            kv[u] = __builtin_nontemporal_load((const u32x4*)(kb + (long)key * 128));
+        }
+    };
+    auto issueV = [&](const T* vb, int base, int k1) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            int key = base + u * KPI + grp;
+            key = key < k1 ? key : k1 - 1;
+            vv[u] = __builtin_nontemporal_load((const u32x4*)(vb + (long)key * 128));
+        }
+    };
+    auto run_pipe = [&](const T* kb, const T* vb, int kfirst, int k1) {
+        if (kfirst >= k1) return;
+        issueK(kb, kfirst, k1);
+        for (int base = kfirst; base < k1; base += NW * KPW) {
+            issueV(vb, base, k1);
+            float sc[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                float kf[EPV]; ET<T>::unpack(kv[u], kf);
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) d = fmaf(q[e], kf[e], d);
+#pragma unroll
+                for (int o_ = LPK / 2; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
+                sc[u] = (base + u * KPI + grp < k1) ? d : -INFINITY;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issueK(kb, base + NW * KPW, k1);                         // next chunk's K (clamped to the last key past the end: one cache line)
+            __builtin_amdgcn_sched_barrier(0);
+            float mx = m_run;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) mx = fmaxf(mx, sc[u]);
+            const float mxs = (mx > -INFINITY) ? mx : 0.f;
+            const float alpha = __expf(m_run - mxs);
+            l_run *= alpha;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) o[e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float p = __expf(sc[u] - mxs);
+                l_run += p;
+                float vf[EPV]; ET<T>::unpack(vv[u], vf);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o[e] = fmaf(p, vf[e], o[e]);
+            }
+            m_run = mx;
+        }
+    };
     auto run = [&](const T* kb, const T* vb, int kfirst, int k1, auto ntl) {
+        if constexpr ((ABL & 16) != 0 && decltype(ntl)::value) { run_pipe(kb, vb, kfirst, k1); return; }
         for (int base = kfirst; base < k1; base += NW * KPW) { issue(kb, vb, base, k1, ntl); consume(base, k1); }
     };
     if (have0) consume(base0, seg_k1);
@@ -491,16 +548,24 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
                               int max_pos, float scale) {
     if (M <= 0) return;
     // few (row, head) blocks (small batch): eight waves per block keep 2x the K/V bytes in flight per CU
-    if ((M * nh <= 512 && pg_tune->attn_waves != 4) || pg_tune->attn_waves == 8)
-        hipLaunchKernelGGL((attn_decode_fused_kernel<T, 7, 8>), dim3(nh, M), dim3(512), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
-                           st, nh, slots, max_pos, scale);
-    else if (pg_tune->attn_variant >= 100 && pg_tune->attn_variant < 108) {      // timing ablations (results wrong by construction)
-#define ATT_ABL(A) case 100 + A: hipLaunchKernelGGL((attn_decode_fused_kernel<T, 7, 4, A>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, nh, slots, max_pos, scale); break;
-        switch (pg_tune->attn_variant) { ATT_ABL(1) ATT_ABL(2) ATT_ABL(3) ATT_ABL(4) ATT_ABL(7) default: break; }
-#undef ATT_ABL
-    } else
-        hipLaunchKernelGGL((attn_decode_fused_kernel<T, 7, 4>), dim3(nh, M), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t,
-                           st, nh, slots, max_pos, scale);
+    // Production: the software-pipelined loop (ABL bit 16): 8-wave blocks 5 deep when the launch has few (row, head) blocks (small batch:
+    // 2x the K/V bytes in flight per CU), 4-wave blocks 6 deep otherwise (7 deep spills in the pipelined form).  attn_variant 100 = the
+    // round-2 non-pipelined 7-deep kernel, 101-107 = timing ablations of the production kernel (results wrong by construction).
+#define ATT_LAUNCH(U, W, A) hipLaunchKernelGGL((attn_decode_fused_kernel<T, U, W, A>), dim3(nh, M), dim3(64 * W), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, nh, slots, max_pos, scale)
+    const int av = pg_tune->attn_variant;
+    const bool small = (M * nh <= 512 && pg_tune->attn_waves != 4) || pg_tune->attn_waves == 8;
+    if (av == 100) { if (small) ATT_LAUNCH(7, 8, 0); else ATT_LAUNCH(7, 4, 0); }
+    else if (av > 100 && av < 108 && !small) {
+        switch (av) {
+            case 101: ATT_LAUNCH(6, 4, 17); break;
+            case 102: ATT_LAUNCH(6, 4, 18); break;
+            case 103: ATT_LAUNCH(6, 4, 19); break;
+            case 104: ATT_LAUNCH(6, 4, 20); break;
+            default: ATT_LAUNCH(6, 4, 23); break;
+        }
+    } else if (small) ATT_LAUNCH(5, 8, 16);
+    else ATT_LAUNCH(6, 4, 16);
+#undef ATT_LAUNCH
 }
 template void launch_attn_decode_fused<float>(hipStream_t, const float*, int, long, float*, float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
 template void launch_attn_decode_fused<bf16>(hipStream_t, const float*, int, long, bf16*, bf16*, bf16*, const float*, const float*, SeqState, int, int, int, int, float);
