@@ -119,7 +119,7 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t a, uint64_t
 
 // One row of (split-K reduce + residual add + RMSNorm) by a 256-thread block (rmsnorm_kernel and the
 // norm blocks of the fused norm+GEMM launch share it).  ``red``: >= 4 floats of LDS.
-template <typename T, int NV, bool SC1 = false, int SB = 4>      // SB: slabs loaded in the up-front batch (4, or 8 for S > 4)
+template <typename T, int NV, bool SC1 = false, int SB = 4, int NT = 256>      // SB: slabs loaded in the up-front batch (4, or 8 for S > 4); NT: threads per row
 __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const float* __restrict__ partial,
                                             int S, long slab, const T* __restrict__ w,
                                             T* __restrict__ xn, int H, float eps, float* red) {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
     u32x2 wv2[NV]; f32x4 wv4[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int i = tid * 4 + j * 1024;
+        const int i = tid * 4 + j * (NT * 4);
         if (xn && i < H) { if constexpr (sizeof(T) == 2) wv2[j] = *(const u32x2*)(w + i); else wv4[j] = *(const f32x4*)(w + i); }
     }
     // ALL of the row's loads go out before the first add: x and the first four slabs of every one of the thread's NV vectors in one
@@ -141,7 +141,7 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
     f32x4 t[NV][SB];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int i = tid * 4 + j * 1024;
+        const int i = tid * 4 + j * (NT * 4);
         const int ic = i < H ? i : 0;                                  // clamped: loads unconditional, results discarded
         v[j] = *(const f32x4*)(xr + ic);
         // branch-free: S == 0 (no slabs, ``partial`` may be null) reads the residual row again and discards it; a conditional load
@@ -154,7 +154,7 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
     }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int i = tid * 4 + j * 1024;
+        const int i = tid * 4 + j * (NT * 4);
         if (i < H) {
 #pragma unroll
             for (int u = 0; u < SB; ++u) if (u < S) v[j] += t[j][u];
@@ -172,13 +172,13 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
             ss += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
         } else v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    ss = block_sum<4>(ss, red);
+    ss = block_sum<NT / 64>(ss, red);
     // the updated residual row is stored AFTER the reduction: in front of it, the block barrier's release waited for the stores'
     // acknowledgements (`s_waitcnt vmcnt(0)` before `s_barrier`), ~1 us of a 5 us kernel
     if (S > 0) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid * 4 + j * 1024;
+            const int i = tid * 4 + j * (NT * 4);
             if (i < H) *(f32x4*)(xr + i) = v[j];
         }
     }
@@ -186,7 +186,7 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
     const float rstd = rsqrtf(ss / (float)H + eps);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int i = tid * 4 + j * 1024;
+        const int i = tid * 4 + j * (NT * 4);
         if (i < H) {
             float o[4];
             if constexpr (sizeof(T) == 2) {
