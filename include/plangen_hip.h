@@ -188,7 +188,8 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *   rng_image_offset (0)  global index of this handle's image 0: prompt-sharded ranks sample exactly what one big batch would
  *   allow_partial_weights (0)  run although required tensors were never loaded (they read as zeros)
  *   stream_gemm (-1 auto)  bit mask of the decode GEMM classes on the v4 kernel (x tile by LDS-DMA): 1 wide-N slabs, 2 narrow-N
- *                       slabs, 4 SwiGLU gate|up, 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue; 0 = v3 everywhere
+ *                       slabs, 4 SwiGLU gate|up, 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue; 0 = v3 everywhere;
+ *                       128 = v3 wide-N blocks of 64 columns / 4 waves instead of 128 columns / 8 waves
  *   wt_store (0)        v3 split-K slabs with write-through (sc1) stores
  *   use_graph (1)       replay the decode step as a hipGraph
  *   share_uncond (1)    prefill / store a batch-constant negative prompt once

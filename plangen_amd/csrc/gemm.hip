@@ -570,6 +570,10 @@ static bool sk3_prod_tiled(hipStream_t s, const bf16* x, const bf16* Wt, float* 
     if (mrows <= 32) return sk3_prod_nck<2, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck);
     // tiled weights: 64-row M blocks for every shape (measured best at M = 128: the second reader of a
     // W tile hits L2, LDS per block halves -> more blocks per CU)
+    // wide N (qkv, gate|up, gen_head at 65..128 rows): 128-column blocks of 8 waves -- the x tile is fetched and staged once per 128
+    // columns instead of once per 64 (loop -11 ms at bs=64); stream_gemm bit 128 keeps the 4-wave block for A/B
+    if (N % 128 == 0 && N >= 4096 && !(pg_tune->stream_gemm >= 0 && (pg_tune->stream_gemm & 128)))
+        return sk3_prod_nck<4, EPI, 8, TILED>(s, x, Wt, out, M, N, K, S, nck);
     return sk3_prod_nck<4, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck);
 }
 
