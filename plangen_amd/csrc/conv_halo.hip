@@ -181,13 +181,18 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
             // kernel adds the tiles of an image in double.  Replaces the separate statistics pass.
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const long m = mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16;
+            for (int mp = 0; mp < 2; ++mp) {                                // 8 fragments per batch: all bias / residual loads up front
+                int rows[8], cols[8]; f32x4 av[8], vo[8];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int col = wc * 64 + nt * 16 + g * 4;
-                    const f32x4 v = ep.final4(0, (int)m, col, acc[mt][nt]);
-                    ep.put4(0, (int)m, col, v);
+                for (int i = 0; i < 8; ++i) {
+                    const int mt = mp * 2 + (i >> 2), nt = i & 3;
+                    rows[i] = (int)(mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16); cols[i] = wc * 64 + nt * 16 + g * 4; av[i] = acc[mt][nt];
+                }
+                ep.template store4_batch<8>(0, 0, rows, cols, av, true, vo);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int nt = i & 3;
+                    const f32x4 v = vo[i];
                     s1[nt] += (v[0] + v[1]) + (v[2] + v[3]);
                     s2[nt] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                 }
@@ -211,10 +216,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
             __syncthreads();                                            // red is rewritten by the next tile
         } else {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const long m = mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16;
+            for (int mp = 0; mp < 2; ++mp) {
+                int rows[8], cols[8]; f32x4 av[8];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) ep.store4(0, 0, (int)m, wc * 64 + nt * 16 + g * 4, acc[mt][nt], vec);
+                for (int i = 0; i < 8; ++i) {
+                    const int mt = mp * 2 + (i >> 2), nt = i & 3;
+                    rows[i] = (int)(mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16); cols[i] = wc * 64 + nt * 16 + g * 4; av[i] = acc[mt][nt];
+                }
+                ep.template store4_batch<8>(0, 0, rows, cols, av, vec);
             }
         }
     }

@@ -229,10 +229,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
                     }
                 }
         } else {
+            // two m-tile rows (8 fragments) per batch: their bias / residual loads go out together (gemm_common.h store4_batch)
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+            for (int mp = 0; mp < 4; ++mp) {
+                int rows[8], cols[8]; f32x4 av[8];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) ep.store4(coff, roff, em0 + mt * 16, en0 + nt * 16, acc[mt][nt], vec);
+                for (int i = 0; i < 8; ++i) { rows[i] = em0 + (mp * 2 + (i >> 2)) * 16; cols[i] = en0 + (i & 3) * 16; av[i] = acc[mp * 2 + (i >> 2)][i & 3]; }
+                ep.template store4_batch<8>(coff, roff, rows, cols, av, vec);
+            }
         }
     }
 #undef G2_MFMA_SECTION

@@ -180,6 +180,61 @@ struct Epi {
         if (e.out_f32 || sizeof(T) == 4) *(f32x4*)((float*)e.out + o) = v;
         else { uint2 q; q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); *(uint2*)((bf16*)e.out + o) = q; }
     }
+    // NF fragments at once, same arithmetic and order as store4(): every bias / residual load of the batch is issued before the first
+    // use (one wave-uniform branch per operand kind, indices clamped into the matrix, stores predicated).  Calling store4() per
+    // fragment compiles to load -> s_waitcnt vmcnt(0) -> load -> s_waitcnt vmcnt(0) -> store for EVERY fragment (the `if (e.bias_n)` /
+    // `if (e.residual)` guards become exec-masked blocks with a drain at each join): two dependent memory round trips per fragment,
+    // 16-32 fragments per tile.  vals_out (optional): the stored values (GroupNorm partials of conv_halo).
+    template <int NF>
+    __device__ __forceinline__ void store4_batch(long coff, long roff, const int (&row)[NF], const int (&col)[NF], const f32x4 (&acc)[NF], bool vec,
+                                                 f32x4* vals_out = nullptr) const {
+        if (!vec) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) { store4(coff, roff, row[i], col[i], acc[i], false); if (vals_out) vals_out[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            return;
+        }
+        int rc[NF], cc[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { rc[i] = row[i] < M ? row[i] : M - 1; cc[i] = col[i] + 4 <= N ? col[i] : N - 4; }
+        f32x4 b[NF], r[NF];
+        float bm[NF];
+        if (e.bias_n) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) b[i] = *(const f32x4*)(e.bias_n + cc[i]);
+        }
+        if (e.bias_m) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) bm[i] = e.bias_m[rc[i]];
+        }
+        if (e.residual) {
+            const long ldr = e.ldr ? e.ldr : e.ldc;
+            if (e.res_f32 || sizeof(T) == 4) {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) r[i] = *(const f32x4*)((const float*)e.residual + roff + (long)rc[i] * ldr + cc[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    const uint2 r2 = *(const uint2*)((const bf16*)e.residual + roff + (long)rc[i] * ldr + cc[i]);
+                    r[i] = (f32x4){bf16_lo(r2.x), bf16_hi(r2.x), bf16_lo(r2.y), bf16_hi(r2.y)};
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            f32x4 v = acc[i];
+            v *= e.scale;
+            if (e.bias_n) v += b[i];
+            if (e.bias_m) v += bm[i];
+            if (e.residual) v += r[i];
+            if (e.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            if (vals_out) vals_out[i] = v;
+            if (row[i] < M && col[i] < N) {
+                const long o = coff + (long)row[i] * e.ldc + col[i];
+                if (e.out_f32 || sizeof(T) == 4) *(f32x4*)((float*)e.out + o) = v;
+                else { uint2 q; q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); *(uint2*)((bf16*)e.out + o) = q; }
+            }
+        }
+    }
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
