@@ -112,12 +112,12 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __r
     }
     // C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {                                          // 16 elements per batch: their bias / residual loads go out together
+        int rows[16], cols[16]; float av[16];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                ep(coff, roff, m0 + wm * 64 + mt * 16 + g * 4 + r, n0 + wn * 64 + nt * 16 + lr, acc[mt][nt][r]);
+        for (int i = 0; i < 16; ++i) { rows[i] = m0 + wm * 64 + mt * 16 + g * 4 + (i & 3); cols[i] = n0 + wn * 64 + (i >> 2) * 16 + lr; av[i] = acc[mt][i >> 2][i & 3]; }
+        ep.template store1_batch<16>(coff, roff, rows, cols, av);
+    }
 }
 
 // ------------------------------------------------------------------------------- fp32 GEMM

@@ -180,6 +180,45 @@ struct Epi {
         if (e.out_f32 || sizeof(T) == 4) *(f32x4*)((float*)e.out + o) = v;
         else { uint2 q; q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); *(uint2*)((bf16*)e.out + o) = q; }
     }
+    // NF scalar elements at once, same arithmetic and order as operator(): loads batched like store4_batch (the 128x128 kernel's C layout
+    // gives a lane single elements of 4 consecutive rows)
+    template <int NF>
+    __device__ __forceinline__ void store1_batch(long coff, long roff, const int (&row)[NF], const int (&col)[NF], const float (&acc)[NF]) const {
+        int rc[NF], cc[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { rc[i] = row[i] < M ? row[i] : M - 1; cc[i] = col[i] < N ? col[i] : N - 1; }
+        float b[NF], bm[NF], r[NF];
+        if (e.bias_n) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) b[i] = e.bias_n[cc[i]];
+        }
+        if (e.bias_m) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) bm[i] = e.bias_m[rc[i]];
+        }
+        if (e.residual) {
+            const long ldr = e.ldr ? e.ldr : e.ldc;
+            if (e.res_f32) {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) r[i] = ((const float*)e.residual)[roff + (long)rc[i] * ldr + cc[i]];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NF; ++i) r[i] = ET<T>::ld((const T*)e.residual + roff + (long)rc[i] * ldr + cc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+            float v = acc[i] * e.scale;
+            if (e.bias_n) v += b[i];
+            if (e.bias_m) v += bm[i];
+            if (e.residual) v += r[i];
+            if (e.act == 1) v = gelu_erf(v);
+            if (row[i] < M && col[i] < N) {
+                const long o = coff + (long)row[i] * e.ldc + col[i];
+                if (e.out_f32) ((float*)e.out)[o] = v; else ET<T>::st((T*)e.out + o, v);
+            }
+        }
+    }
     // NF fragments at once, same arithmetic and order as store4(): every bias / residual load of the batch is issued before the first
     // use (one wave-uniform branch per operand kind, indices clamped into the matrix, stores predicated).  Calling store4() per
     // fragment compiles to load -> s_waitcnt vmcnt(0) -> load -> s_waitcnt vmcnt(0) -> store for EVERY fragment (the `if (e.bias_n)` /
