@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256) void dma_order_kernel(const unsigned* __restri
     const long wave = (long)blockIdx.x * 4 + w;
     unsigned bad = 0, acc = 0;
     for (int it = 0; it < iters; ++it) {
-        const unsigned* src = cold + ((long)it * gridDim.x * 4 + wave) * stride_words + l * 4;
+        // mode bit 16: the DMA instruction spans FOUR cold 4 KiB pages (16 lanes each), like the x-tile pieces of the decode GEMM
+        const unsigned* src = (mode & 16) ? cold + ((long)it * gridDim.x * 4 + wave) * stride_words * 4 + (long)(l >> 4) * stride_words + (l & 15) * 4
+                                          : cold + ((long)it * gridDim.x * 4 + wave) * stride_words + l * 4;
         *(uint4*)&lds[w][l * 4] = make_uint4(0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu, 0xdeadbeefu);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         u32x4 hv;
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(256) void dma_order_kernel(const unsigned* __restri
         u32x4 got;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(got) : "v"((unsigned)(size_t)&lds[w][l * 4]) : "memory");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(hv) :: "memory");
-        const unsigned idx = (unsigned)(((long)it * gridDim.x * 4 + wave) * stride_words + l * 4);
+        const unsigned idx = (mode & 16) ? (unsigned)(((long)it * gridDim.x * 4 + wave) * stride_words * 4 + (long)(l >> 4) * stride_words + (l & 15) * 4)
+                                         : (unsigned)(((long)it * gridDim.x * 4 + wave) * stride_words + l * 4);
         bad += (got[0] != idx * 2654435761u) || (got[3] != (idx + 3) * 2654435761u);
         acc += hv[0];
     }
@@ -370,7 +373,7 @@ __global__ void fill_hash_kernel(unsigned* p, long n) {
 }
 extern "C" int pg_bench_dma_order(int blocks, int iters, int mode, unsigned* fails_out, unsigned* checks_out) {
     const long stride_words = 1024;                 // 4 KiB apart: every DMA touches fresh lines (and pages)
-    const long n = (long)iters * blocks * 4 * stride_words;
+    const long n = (long)iters * blocks * 4 * stride_words * ((mode & 16) ? 4 : 1);
     unsigned *cold, *hot, *fails, *sink;
     if (hipMalloc((void**)&cold, n * 4) != hipSuccess) return -3;
     hipMalloc((void**)&hot, 4096); hipMalloc((void**)&fails, 4); hipMalloc((void**)&sink, 4);

@@ -612,12 +612,12 @@ static bool sk3_prod(hipStream_t s, const bf16* x, const bf16* W, float* out, in
 //               issue X(c+XD-1) into the slot of X(c-1)
 //               MFMA on X(c), W(c)     (the compiler waits for W(c))
 //               issue W(c+WD) into W(c)'s registers
-constexpr int sk4_wait_count(int c, int NCK, int XD, int WD, int MT) {
+constexpr int sk4_wait_count(int c, int NCK, int XD, int WD, int MT, int ahead = 0) {      // ahead = 1: chunk c+1 (not only c) retired at chunk c's barrier
     int ops = 0, lastX[64] = {};
     for (int p = 0; p < XD - 1 && p < NCK; ++p) { ops += MT; lastX[p] = ops; }
     for (int p = 0; p < WD && p < NCK; ++p) ops += 4;
     for (int it = 0; it < NCK; ++it) {
-        if (it == c) return ops - lastX[c];
+        if (it == c) return ops - lastX[(c + ahead < NCK) ? c + ahead : NCK - 1];
         if (it + XD - 1 < NCK) { ops += MT; lastX[it + XD - 1] = ops; }
         if (it + WD < NCK) ops += 4;
     }
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
     sk4_static_for<0, NCK, XD, WD, MTW>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
         if constexpr (!(ABL & 1)) {
-            if constexpr (ABL & 8) wait_vmcnt<0>(); else wait_vmcnt<sk4_wait_count(c, NCK, XD, WD, MTW)>();      // ABL 8 (bench): drain everything
+            if constexpr (ABL & 8) wait_vmcnt<0>(); else wait_vmcnt<sk4_wait_count(c, NCK, XD, WD, MTW, (ABL & 64) ? 1 : 0)>();      // ABL 8 (bench): drain everything
             stamp();
             __builtin_amdgcn_s_barrier();
             stamp();
@@ -889,6 +889,9 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
 // pg_tune->stream_gemm bits: 1 wide-N slabs (qkv, gen_head, lm_head), 2 narrow-N slabs (o, down), 4 SwiGLU gate|up,
 // 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue instead of the direct one.
 template <int EPI>
+// Every production instantiation retires an x chunk ONE BARRIER BEFORE its first read (ABL bit 64, ring one slot deeper to keep the
+// prefetch distance): reading right behind the barrier that follows the issuing wave's counted wait is not enough on gfx950 -- in ~0.5 %
+// of COLD launches (fresh operands: tools/op_gemm_stress.py) a reader wave saw the old bytes of a wave's LAST 1 KiB piece.
 static bool sk4_prod(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
     // -1 (default): what measured faster IN the decode loop on MI355X (tools/ab_loop.sh, profiles/r02_b_decode_gemm_investigation.md): every class at
     // M <= 64 (48 KiB blocks, 2-3 per CU: loop -3.3 % at bs=32, -6.2 % at bs=8), only the narrow-N slabs at M = 128 (-1.5 %;
@@ -900,20 +903,20 @@ static bool sk4_prod(hipStream_t s, const bf16* x, const bf16* Wt, float* out, i
     if (SW ? !(sg & 4) : !(sg & (wide ? 1 : 2))) return false;
     if (M > 64) {
         if constexpr (SW) {
-            if (sg & 16) return sk4_nck<8, 3, 3, 1, 1>(s, x, Wt, out, M, N, K, S);
-            return sk4_nck<8, 3, 3, 3, 1>(s, x, Wt, out, M, N, K, S);
+            if (sg & 16) return sk4_nck<8, 4, 3, 1, 1, 64>(s, x, Wt, out, M, N, K, S);
+            return sk4_nck<8, 4, 3, 3, 1, 64>(s, x, Wt, out, M, N, K, S);
         } else {
-            if (wide) return sk4_nck<8, 3, 3, EPI, 1>(s, x, Wt, out, M, N, K, S);
-            return sk4_nck<4, 3, 3, EPI, 2>(s, x, Wt, out, M, N, K, S);
+            if (wide) return sk4_nck<8, 4, 3, EPI, 1, 64>(s, x, Wt, out, M, N, K, S);
+            return sk4_nck<4, 4, 3, EPI, 2, 64>(s, x, Wt, out, M, N, K, S);
         }
     }
     if (M > 16) {                               // 17..64 rows: one 64-row block (rows beyond M clamped; bs=16 loop -1.6 %, bs=32 -3.3 %)
-        if constexpr (SW) { if (sg & 16) return sk4_nck<4, 3, 3, 1, 2>(s, x, Wt, out, M, N, K, S); }
-        return sk4_nck<4, 3, 3, EPI, 2>(s, x, Wt, out, M, N, K, S);
+        if constexpr (SW) { if (sg & 16) return sk4_nck<4, 4, 3, 1, 2, 64>(s, x, Wt, out, M, N, K, S); }
+        return sk4_nck<4, 4, 3, EPI, 2, 64>(s, x, Wt, out, M, N, K, S);
     }
     if (sg & 8) {
-        if constexpr (SW) { if (sg & 16) return sk4_nck<1, 4, 3, 1, 4>(s, x, Wt, out, M, N, K, S); }
-        return sk4_nck<1, 4, 3, EPI, 4>(s, x, Wt, out, M, N, K, S);
+        if constexpr (SW) { if (sg & 16) return sk4_nck<1, 5, 3, 1, 4, 64>(s, x, Wt, out, M, N, K, S); }
+        return sk4_nck<1, 5, 3, EPI, 4, 64>(s, x, Wt, out, M, N, K, S);
     }
     return false;
 }

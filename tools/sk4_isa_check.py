@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Static check of the v4 decode GEMM's hand-counted waits against the COMPILED code.
 
-For every gemm_sk4_kernel instantiation (ABL == 0) in `hipcc -S` output of gemm.hip: walk the VMEM instructions in program order
+For every gemm_sk4_kernel instantiation (no ablation bits; bit 64 = early retire, checked with the stricter rule) in `hipcc -S` output of gemm.hip: walk the VMEM instructions in program order
 (global_load_lds = x DMA piece, `global_load_dwordx4 ... nt` = W fragment load, stores), and at every `s_waitcnt vmcnt(N)`
   * in front of the s_barrier of chunk c: every DMA piece of x chunk c must be among the retired ops (ops issued - N >= index of its last piece);
   * every MFMA: the W fragment registers it reads must come from retired loads;
+  * every DMA piece of x chunk k is issued after barrier k - XD + 1 (the readers of the slot it overwrites are past their reads);
   * every ds_read_b128 of the x ring sits between the barrier of the chunk whose slot it addresses and the next barrier
     (direct-store epilogues only: the LDS-transposed epilogues reuse the ring).
 VMEM ops retire in issue order (tools/dma_order_probe.py), so this is exactly the condition the kernel relies on.
@@ -45,23 +46,29 @@ while i < len(lines):
         elif t.startswith("v_mfma"): ev.append(("M", re.findall(r"(v\[\d+:\d+\])", t)))
         j += 1
     i = j
-    if ABL != 0:
-        continue
+    if ABL & ~64:
+        continue                                      # timing ablations / stamped variants
+    AH = 1 if ABL & 64 else 0                         # early retire: chunk c+1 must be retired at barrier c (read one barrier after its retirement)
     XPW = MT * 4 // (NWN * MS)
     issued = 0; retired = 0; xs = []; wreg = {}        # wreg: W destination register range -> issue index of the load that last wrote it
     chunk = -1; ok = True; why = ""
     for kind, val in ev:
         if kind in ("X", "W", "L", "S"):
             issued += 1
-            if kind == "X": xs.append(issued)
+            if kind == "X":
+                xs.append(issued)
+                kx = (len(xs) - 1) // XPW                   # x chunk this piece belongs to; it overwrites the ring slot of chunk kx - XD
+                if kx - (XD - 1) > chunk:                   # ... whose last readers are only known to be done after barrier kx - XD + 1
+                    ok = False; why = f"x piece of chunk {kx} issued before barrier {kx - XD + 1} (only {chunk + 1} barriers passed): ring slot may still be read"; break
             if kind == "W": wreg[val] = issued
         elif kind == "wait":
             retired = max(retired, issued - val)          # in-order retirement: all but the `val` youngest ops are done
         elif kind == "B":
             chunk += 1
             if chunk < NCK:
-                if len(xs) < (chunk + 1) * XPW: ok = False; why = f"chunk {chunk}: its x pieces were not issued before the barrier"; break
-                need = xs[(chunk + 1) * XPW - 1]
+                tgt = min(chunk + AH, NCK - 1)
+                if len(xs) < (tgt + 1) * XPW: ok = False; why = f"chunk {chunk}: x pieces of chunk {tgt} were not issued before the barrier"; break
+                need = xs[(tgt + 1) * XPW - 1]
                 if retired < need: ok = False; why = f"barrier {chunk}: x piece #{need} of chunk {chunk} may still be in flight (retired {retired})"; break
         elif kind == "R":
             # x fragment read: must sit between barrier c and barrier c+1 of the chunk whose ring slot it addresses (a read that sank
