@@ -274,3 +274,34 @@ def test_decode_gemm_back_to_back_race_screen(M, N, K, S):
         rc = lib.pg_bench_skinny_verify(M, N, K, 2, S, 1, 100, C.byref(md), C.byref(mr))
         assert rc == 0
         assert md.value <= 2e-3 * mr.value, (md.value, mr.value)
+
+
+def test_decode_gemm_cold_launches(tiny_cfg, tiny_weights):
+    """ONE launch of the tiled decode GEMM at a time on an otherwise IDLE GPU (fresh device copies of host operands, 0.15 s pause between
+    launches), 120 times: the shape and path that read a wave's last LDS-DMA piece stale in ~0.5 % of such cold launches before every chunk
+    was retired one barrier ahead of its first read.  Back-to-back launches never showed it, with or without fresh
+    memory; with the previous kernel this test fails in roughly one run of three at 400 iterations -- the structural guard is
+    tests/test_isa_check.py, this is the empirical one."""
+    e = _eng(tiny_cfg, tiny_weights, "bf16")
+    M, N, K = 64, 6144, 2048
+    g = torch.Generator().manual_seed(11)
+    sets = []
+    for _ in range(6):
+        a = _round(torch.randn(M, K, generator=g), "bf16")
+        w = _round(torch.randn(N, K, generator=g) * 0.05, "bf16")
+        sets.append((a, w, (a.cuda().double() @ w.cuda().double().t())))
+    junk = []
+    import time
+    for it in range(120):
+        a, w, ref = sets[it % len(sets)]
+        if it % 3 == 0:
+            junk.append(torch.empty((1 + it % 7) * 1_000_003, device="cuda"))
+        if len(junk) > 4:
+            junk.pop(0)
+        time.sleep(0.15)                                           # the GPU goes idle between launches: that, not fresh memory, is what 'cold' needs
+        out = e.op_gemm(a, w, 4)                                   # host tensors: fresh device copies every call
+        d = (out.double() - ref).abs()
+        tol = 2e-4 * ref.abs().max().item() + 1e-4
+        if d.max().item() >= tol:
+            idx = (d >= tol).nonzero()
+            raise AssertionError((it, d.max().item(), sorted(set(idx[:, 0].tolist()))[:16], sorted(set((idx[:, 1] // 16).tolist()))[:16]))
