@@ -32,6 +32,7 @@ __global__ void fill_const_kernel(bf16* p, long n, float v) {
 extern "C" int pg_bench_skinny(int M, int N, int K, int variant, int S, int iters, int with_consumer, float* us_out) {
     const long wbytes = (long)N * K * 2;
     int nbuf = (int)((600L << 20) / wbytes) + 1; if (nbuf > 64) nbuf = 64; if (nbuf < 2) nbuf = 2;
+    if (const char* e = getenv("PG_BENCH_NBUF")) nbuf = atoi(e) > 0 ? atoi(e) : nbuf;   // 1 = weights stay in the Infinity Cache
     std::vector<bf16*> Ws(nbuf);
     for (auto& p : Ws) { if (hipMalloc((void**)&p, wbytes) != hipSuccess) return -2; hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, p, (long)N * K, 7u); }
     bf16 *x, *xn; float *out, *res;
