@@ -333,7 +333,7 @@ def run_rank(args):
                                "timed_every_nth_step": args.time_stride}
             # Event timing of SHORT kernels is pessimistic: an event pair around nothing already costs a few us in this eager pass
             # ("event_pair_overhead_us"; measured ~4.7 us, about half of it lands inside a timed interval).  "avg_launch_us" is
-            # the raw event interval; the rocprofv3 --kernel-trace averages of the graph-replayed loop are in profiles/.
+            # the raw event interval; the rocprofv3 --kernel-trace averages of the replayed loop are in profiles/.
             empty = cls.get("empty_event_pair", {"ms_sum": 0.0, "launches": 0})
             out["roofline"]["event_pair_overhead_us"] = empty["ms_sum"] / empty["launches"] * 1e3 if empty["launches"] else None
             classes = {}
@@ -364,7 +364,7 @@ def run_rank(args):
                 ph = {"events_weight_gbs": dby / (dsum * 1e-3) / 1e9, "events_frac": dby / (dsum * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "events_ms_per_step": dsum / nsteps_timed}
                 # The event-timed figure carries one event pair (~4.6 us) per launch on ~150 short launches per step.  Second, precise
-                # measurement: the SAME decode step replayed as a hipGraph WITHOUT its 24 attention launches ("skip_attn", results
+                # measurement: the SAME decode step replayed (as the timed region launches it) WITHOUT its 24 attention launches ("skip_attn", results
                 # are garbage by construction) -- what is left is the GEMM + norm phase plus gen_head / sampler, whose event-timed
                 # share (5 launches per step) is subtracted.
                 Tn = min(T, 96)
@@ -382,7 +382,7 @@ def run_rank(args):
                 g_ms = t2["decode_ms"] / Tn - head_ms
                 w_step = dby / nsteps_timed
                 ph.update({"ms_per_step": g_ms, "weight_gbs": w_step / (g_ms * 1e-3) / 1e9, "frac": w_step / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "method": "decode step graph replayed without attention launches (%d steps) minus event-timed gen_head + sampler "
+                           "method": "decode step replayed without its attention launches (%d steps, same launch mode as the timed region) minus event-timed gen_head + sampler "
                                      "(%.3f ms/step); events_* = sum of per-launch HIP-event intervals" % (Tn, head_ms)})
                 out["roofline"]["decode_gemm_norm_phase"] = ph
     if world > 1:

@@ -191,7 +191,8 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *                       slabs, 4 SwiGLU gate|up, 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue; 0 = v3 everywhere;
  *                       128 = v3 wide-N blocks of 64 columns / 4 waves instead of 128 columns / 8 waves
  *   wt_store (0)        v3 split-K slabs with write-through (sc1) stores
- *   use_graph (1)       replay the decode step as a hipGraph
+ *   use_graph (0)       replay the decode step as a hipGraph (one launch per step from the host; env PG_USE_GRAPH=1).  Off by default:
+ *                       same-stream launches of the ~175 kernels of a step measure 1-3 % faster than graph replay
  *   share_uncond (1)    prefill / store a batch-constant negative prompt once
  *   flash_prefill (1)   MFMA flash attention for prefill (0: per-query streaming kernel)
  *   fuse_rope (1)       RoPE + KV append inside the decode-attention kernel

@@ -147,6 +147,7 @@ def test_decode_graph_survives_fresh_buffers_seeds_and_temperatures(tiny_cfg, ti
     output / forcing tensors reach it through library-owned device memory.  Calls with fresh tensors must keep
     producing the right tokens (greedy == oracle), seeded sampling must be reproducible, and seeds must matter."""
     e = get_engine(tiny_cfg, tiny_weights, "f32")
+    e.set_option("use_graph", 1)          # off by default since the end of round 2 (stream launches measure faster); this test is about the graph
     g = torch.Generator().manual_seed(71)
     cond = [torch.randint(8, tiny_cfg.vocab, (n,), generator=g).tolist() for n in (7, 11)]
     neg = torch.randint(8, tiny_cfg.vocab, (5,), generator=g).tolist()
@@ -166,6 +167,7 @@ def test_decode_graph_survives_fresh_buffers_seeds_and_temperatures(tiny_cfg, ti
     assert torch.equal(e.decode_image_tokens(T=10, cfg_weight=5.0, temperature=0.0, force_tokens=force).cpu(), ref_f)
     e.prefill(ids, pad)
     assert torch.equal(e.decode_image_tokens(T=7, cfg_weight=5.0, temperature=0.0).cpu(), ref[:, :7])
+    e.set_option("use_graph", 0)
 
 
 def test_sampled_frequencies_follow_softmax_chi_square(tiny_cfg, tiny_weights, ocfg):

@@ -98,7 +98,7 @@ def test_graph_equals_eager_and_is_deterministic():
         e.set_option("use_graph", use_graph)
         e.prefill(ids, pad)
         outs.append(e.decode_image_tokens(T=16, cfg_weight=5.0, temperature=0.0).cpu())
-    e.set_option("use_graph", 1)
+    e.set_option("use_graph", 0)          # back to the default (stream launches)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
