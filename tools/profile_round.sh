@@ -22,3 +22,5 @@ python3 $ROOT/tools/pmc_traffic.py $F $W --tokens 24 --json $OUT/pmc_attn_$tag.j
 for pat in gemm_skinny3 gemm_sk4 rmsnorm_kernel; do
   echo "-- $pat"; python3 $ROOT/tools/pmc_dump.py $pat $F $W
 done | tee $OUT/pmc_${tag}_gemm.txt
+# the raw databases exceed gpurun_out's 64 MiB return limit when the loop is stream-launched: keep the summaries only
+rm -rf $OUT/prof_$tag $OUT/pmc_${tag}_FETCH_SIZE $OUT/pmc_${tag}_WRITE_SIZE
