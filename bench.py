@@ -27,6 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # the ROCm 7.2 default, pinned: stream launches need it (plangen_amd/__init__.py)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable float4 copy)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
