@@ -344,6 +344,67 @@ def golden_full_width(T=48):
 
 
 @torch.no_grad()
+def golden_small_batch(T=288, B=8, NEG=200):
+    """VERDICT r2 task 1: the SMALL-BATCH kernel instantiations (BASELINE configs[1], bs=8 -> 16 CFG rows) need a reference whose
+    key counts make their loops iterate: 8 pairs, L = 256, cond lengths U{160..256}, ONE shared NEG-token negative prompt
+    (200 > the 160 keys the 8-wave decode-attention block peels, so the shared-prefix loop iterates too), T = 288 greedy steps
+    (cond rows end with 448-544 keys, uncond rows with 200 shared + 288 private).  Same seeded full-width weights as
+    ``golden_full_width``; driven by the installed transformers LlamaModel like plangen_base.py:567-607."""
+    torch.set_num_threads(8)
+    cfg = R.OracleCfg(**FULLW)
+    W = R.make_weights(cfg, seed=3)
+    g = torch.Generator().manual_seed(23)
+    neg = torch.randint(8, cfg.vocab, (NEG,), generator=g).tolist()
+    neg[0] = 1
+    cond = []
+    for b in range(B):
+        n = 256 if b == 0 else int(torch.randint(160, 257, (1,), generator=g))
+        row = torch.randint(8, cfg.vocab, (n,), generator=g).tolist()
+        row[0] = 1
+        cond.append(row)
+    ids, mask = R.t2i_infer_collate_batch(cond, neg, cfg.pad_id, cfg.img_tokens)
+    Rr, L = ids.shape
+    assert (Rr, L) == (2 * B, 256)
+    model = hf_llama(cfg, W)
+    inputs_embeds = model.get_input_embeddings()(ids.long())
+    tokens = torch.zeros((B, T), dtype=torch.int)
+    gvocab = torch.Generator().manual_seed(29)
+    vsel = torch.randperm(cfg.img_vocab, generator=gvocab)[:128].sort().values
+    top_v, top_i, sel_logits, last_hidden = [], [], [], []
+    outputs = None
+    for i in range(T):
+        outputs = model(inputs_embeds=inputs_embeds, attention_mask=mask, use_cache=True,
+                        past_key_values=outputs.past_key_values if i != 0 else None)
+        h_last = outputs.last_hidden_state[:, -1, :]
+        if i % 32 == 0 or i == T - 1:
+            last_hidden.append(h_last.clone())
+        logits = R.gen_head(W, h_last)
+        logit_cond, logit_uncond = logits[0::2, :], logits[1::2, :]
+        logits = logit_uncond + 5.0 * (logit_cond - logit_uncond)
+        tv, ti = logits.topk(4, dim=-1)
+        top_v.append(tv.clone()); top_i.append(ti.int().clone())
+        sel_logits.append(logits[:, vsel].clone())
+        next_token = torch.argmax(logits, dim=-1, keepdim=True)
+        tokens[:, i] = next_token.squeeze(-1)
+        next_token = torch.cat([next_token.unsqueeze(1), next_token.unsqueeze(1)], dim=1).view(-1)
+        inputs_embeds = R.prepare_gen_img_embeds(W, next_token).unsqueeze(1)
+        if i % 32 == 0:
+            print("  small-batch reference step", i, flush=True)
+    top_v = torch.stack(top_v); top_i = torch.stack(top_i); sel_logits = torch.stack(sel_logits)
+    mine_tok, mine_logits = R.sample_image(W, cfg, R.embed_tokens(W, ids), mask, 5.0, n_tokens=T, return_logits=True)
+    assert torch.equal(mine_tok, tokens)
+    err = (mine_logits[:, :, vsel] - sel_logits).abs().max().item()
+    assert err < 2e-3, err
+    pad = (L - mask[:, :L].sum(-1)).int()
+    np.savez_compressed(os.path.join(OUT, "sample_image_b8_long.npz"),
+                        ids=ids.numpy().astype(np.int16), pad=pad.numpy(), tokens=tokens.numpy(),
+                        top_v=top_v.numpy(), top_i=top_i.numpy(), vsel=vsel.numpy().astype(np.int32), sel_logits=sel_logits.numpy(),
+                        hid_steps=np.array([i for i in range(T) if i % 32 == 0 or i == T - 1]),
+                        last_hidden=torch.stack(last_hidden).numpy(), neg_len=NEG, wsum=wsum(W))
+    print("small-batch sample_image ok; oracle-vs-transformers logits err", err)
+
+
+@torch.no_grad()
 def golden_siglip_crosscheck():
     """a13 / f2: timm is not installed, so the reference's own ``VisionTransformer`` class (siglip_vit.py) cannot be
     instantiated here and the SigLIP row stays PARITY UNPINNED.  What CAN be done: an independent implementation of the
@@ -421,6 +482,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "fullwidth":
         golden_full_width()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "smallbatch":
+        golden_small_batch()
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     golden_projector()
@@ -428,6 +492,7 @@ def main():
     golden_llama_and_sampling()
     golden_vq_full()
     golden_full_width()
+    golden_small_batch()
     golden_text()
     golden_siglip_crosscheck()
 

@@ -229,7 +229,8 @@ def test_decode_swiglu_gemm_epilogue(tiny_cfg, tiny_weights, M, I, K):
 
 @pytest.mark.parametrize("H,NV", [(2048, 2), (4096, 4)])
 def test_rmsnorm_wide_rows(tiny_cfg, tiny_weights, H, NV):
-    """rmsnorm_kernel<bf16, 2> (H = 2048: the bench's instantiation) and <bf16, 4>, with 4 split-K slabs."""
+    """rmsnorm512_kernel (512 threads per 2048-wide row: the instantiation every decode step runs at H = 2048) and the generic
+    rmsnorm_kernel at H = 4096, with 4 split-K slabs."""
     e = _eng(tiny_cfg, tiny_weights, "bf16")
     g = torch.Generator().manual_seed(H)
     M = 128

@@ -116,3 +116,31 @@ def test_fullwidth_fixture_is_consistent():
     assert all((ids[r, 160:] == ids[1, 160:]).all() for r in range(1, 128, 2))
     assert np.array_equal(g["top_i"][..., 0].T, g["tokens"])
     assert (g["top_v"][..., 0] >= g["top_v"][..., 1]).all()
+
+
+def test_smallbatch_long_fixture_is_consistent():
+    """sample_image_b8_long.npz (8 pairs, shared 200-token negative prompt, 288 steps): inputs have the shape that makes the
+    small-batch decode kernels iterate (tests/test_gpu_smallbatch.py) and the tokens are argmaxes of the stored logits."""
+    g = load_golden("sample_image_b8_long.npz")
+    ids, pad, T = g["ids"], g["pad"], g["tokens"].shape[1]
+    neg = int(g["neg_len"])
+    assert ids.shape == (16, 256) and T == 288 and neg == 200 and (pad[1::2] == 256 - neg).all()
+    assert all((ids[r, 256 - neg:] == ids[1, 256 - neg:]).all() for r in range(1, 16, 2))
+    assert pad[0] == 0 and pad[0::2].max() <= 96
+    assert np.array_equal(g["top_i"][..., 0].T, g["tokens"])
+    assert abs(float(g["wsum"]) - float(load_golden("sample_image_fullwidth.npz")["wsum"])) < 1e-3
+
+
+def test_smallbatch_long_fixture_oracle_reproduces_first_steps():
+    """The oracle restatement on the 16-row full-width fixture: first 3 greedy steps (CPU seconds) equal the stored tokens and
+    logits; make_golden asserted all 288 at generation time."""
+    from fullwidth_cfg import FULLW
+    g = load_golden("sample_image_b8_long.npz")
+    cfg = R.OracleCfg(**FULLW)
+    W = R.make_weights(cfg, seed=3)
+    ids = torch.from_numpy(g["ids"].astype(np.int64)).int()
+    mask = torch.cat([(torch.arange(256)[None] >= torch.from_numpy(g["pad"])[:, None]).int(),
+                      torch.ones(16, cfg.img_tokens, dtype=torch.int)], dim=1)
+    toks, logits = R.sample_image(W, cfg, R.embed_tokens(W, ids), mask, 5.0, n_tokens=3, return_logits=True)
+    assert np.array_equal(toks.numpy(), g["tokens"][:, :3])
+    assert np.abs(logits[:, :, torch.from_numpy(g["vsel"]).long()].numpy() - g["sel_logits"][:3]).max() < 2e-3
