@@ -19,6 +19,7 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -130,21 +131,55 @@ def free_port():
     return p
 
 
-def spawn_ranks(n, argv):
-    """Start ``n`` fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), wait, relay
-    rank 0's stdout.  The parent has not touched the GPU (no torch.cuda call, no HIP call) and never execs."""
+def spawn_ranks(n, argv, poll_s=0.2, grace_s=5.0):
+    """Start ``n`` fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relay rank 0's stdout.
+    The parent has not touched the GPU (no torch.cuda call, no HIP call) and never execs.  ALL children are polled: on the first
+    non-zero exit the others are terminated (SIGTERM, SIGKILL after ``grace_s``) and the launcher returns non-zero at once --
+    a rank that dies before a collective would otherwise leave the survivors in RCCL until the watchdog fires (minutes)."""
+    import tempfile
+    import threading
     port = os.environ.get("MASTER_PORT") or str(free_port())
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PG_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+                                      stdout=out0 if r == 0 else None, start_new_session=True))
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed} exited with rc {rcs[failed]}; terminating the other ranks\n")
+        live = [p for r, p in enumerate(procs) if rcs[r] is None]
+        for p in live:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)          # the rank's own process group (start_new_session): exact PIDs, no pattern
+            except ProcessLookupError:
+                pass
+        t_end = time.time() + grace_s
+        for p in live:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                p.wait()
+        rcs = [p.returncode for p in procs]
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
@@ -161,7 +196,12 @@ def launch_check(args, world, rank):
     assert world == args.gpus, (world, args.gpus)
     assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ.get("PG_DIST_TIMEOUT_S", "300"))))
+    die = os.environ.get("PG_TEST_DIE_RANK")                # test hook: this rank exits before the first collective
+    if die is not None and int(die) == rank:
+        sys.stderr.write(f"bench.py: rank {rank} dying on request (PG_TEST_DIE_RANK)\n")
+        os._exit(7)
     t = torch.tensor([float(rank + 1)])
     if world > 1:
         dist.all_reduce(t)
@@ -202,10 +242,12 @@ def run_rank(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PG_DIST_BACKEND", "nccl")    # "nccl" is RCCL on ROCm
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("PG_DIST_TIMEOUT_S", "300")))      # finite: a dead peer fails the collective
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     cfg = PlanGenConfig.tiny() if args.tiny else PlanGenConfig.janus_pro_1b()
     L = args.prompt_len

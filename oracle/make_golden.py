@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import importlib.util
 import os
+import re
 import sys
 import types
 
@@ -468,6 +469,17 @@ def golden_text():
         prompt = sft if stage1 else sft + "<begin_of_image>"            # plangen_base.py:252-255
         assert R.wrap_uni_prompt_text(caption, grounding, stage1) == prompt, (caption, grounding)
         out.append(dict(caption=caption, grounding=grounding, in_stage1=stage1, prompt=prompt))
+    # wrap_mmu_prompt (plangen_base.py:263-279) as VLChatProcessor.process_one renders it (processing_vlm.py:290-296: ITS system
+    # prompt, read from the class attribute's source text since the module needs PIL / transformers processors to import)
+    src = open("/root/reference/three_party/Janus/janus/models/processing_vlm.py").read()
+    m = re.search(r"system_prompt = \((.*?)\n    \)", src, re.S)
+    system_prompt = "".join(re.findall(r'"(.*?)"', m.group(1)))
+    for question, answer in (("Describe the layout of the image.", ""), ("  what is on the table?\n", ""), ("caption", "a cat")):
+        conv = conv_mod.get_conv_template("deepseek")
+        conv.set_system_message(system_prompt)
+        for role, content in (("<|User|>", f"<image_placeholder>\n{question}"), ("<|Assistant|>", f"{answer}")):
+            conv.append_message(role, content.strip())
+        out.append(dict(mmu_question=question, mmu_answer=answer, prompt=conv.get_prompt().strip()))
     json.dump(out, open(os.path.join(OUT, "text_golden.json"), "w"), ensure_ascii=False, indent=1)
     print("text template ok:", len(out), "cases")
 

@@ -110,7 +110,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
             // second group runs one barrier behind, so one wave per SIMD reads LDS while the other runs MFMAs.
             // Ring discipline under the stagger: W(t+2) is staged in phase t into the slot read in phase t-2;
             // W(t+1) is retired by vmcnt(2) in phase t and read in phase t+1.
+            // Round 3: the halo and W(0) are retired here and read by the first wave group right behind the barrier -- the same-phase
+            // form the staging rule forbids (tools/dma_isa_check.py) -- so a second barrier separates retirement from the first read
+            // (once per 8x32 tile; both groups pass it, the barrier counts stay equal).
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
             if (wr >= 2) asm volatile("s_barrier" ::: "memory");
         }

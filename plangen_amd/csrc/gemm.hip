@@ -665,8 +665,10 @@ __device__ __forceinline__ void sk4_mfma_chunk(const char* xt, int lr, int g, co
         bf16x8 a[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(rp + so[i]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[0] = sk4_mfma<SWAP>(a[i], wc[i], acc[0]);
+        __builtin_amdgcn_sched_barrier(0);      // the ds_reads / MFMAs of a chunk stay between its barrier and the next one (the DMA that re-stages the slot follows that barrier)
     } else {
         constexpr int NP = MT / 2;
         bf16x8 af[2][2][4];

@@ -82,7 +82,7 @@ class System:
         self.vl_gpt = MultiModalityCausalLM(engine)
         self.args = args or SimpleNamespace(seed=cfg.seed, parallel_size=1, cfg_weight=cfg.cfg_weight,
                                             temperature=cfg.temperature, use_teacher_forcing=False,
-                                            debug_max_seq_len=None, janus_hw=cfg.img_size, neg_prompt="")
+                                            debug_max_seq_len=None, janus_hw=cfg.img_size, neg_prompt="", use_neg_box=False)
         self.image_token_num_per_image = cfg.img_tokens
         self.device = engine.device
 
@@ -260,6 +260,13 @@ class System:
             m = mask[:, :L]
             cond = [ids[i][m[i].bool()].tolist() for i in range(ids.shape[0])]
             neg = batch.get("neg_inputs_ids")
+            if getattr(self.args, "use_neg_box", False):
+                # plangen_base.py:652-670: ONE negative prompt PER SAMPLE, wrap_uni_prompt(neg_base_caption, neg_gt_grounding)
+                if "neg_base_caption" in batch and self.codec is not None:
+                    neg = [self.wrap_uni_prompt(c, g)[1].tolist() for c, g in zip(batch["neg_base_caption"], batch["neg_gt_grounding"])]
+                elif not (neg is not None and len(neg) and isinstance(neg[0], (list, tuple, torch.Tensor))):
+                    raise PlanGenError("use_neg_box=True needs batch['neg_base_caption'] / ['neg_gt_grounding'] (with a tokenizer) "
+                                       "or one pre-tokenised negative prompt per sample in batch['neg_inputs_ids']")
             if neg is None:
                 neg = self.wrap_uni_prompt(getattr(self.args, "neg_prompt", ""), "")[1].tolist()
             cfg_ids, cfg_mask = self.t2i_infer_collate_batch(cond, neg)

@@ -24,6 +24,12 @@ ROLES = ("<|User|>", "<|Assistant|>")                 # conversation.py:300
 SEP, SEP2 = "\n\n", "<｜end▁of▁sentence｜>"            # conversation.py:304-305
 IMAGE_START_TAG = "<begin_of_image>"                  # processing_vlm.py:89
 IMAGE_TAG = "<image_placeholder>"                     # processing_vlm.py:88
+IMAGE_END_TAG = "<end_of_image>"                      # processing_vlm.py:90
+# VLChatProcessor.system_prompt (processing_vlm.py:78-82): what process_one / __call__ pass to the sft template (:292-296), i.e.
+# what wrap_mmu_prompt's prompts start with (wrap_uni_prompt passes system_prompt="" instead, plangen_base.py:245-249)
+MMU_SYSTEM_PROMPT = ("You are a helpful language and vision assistant. "
+                     "You are able to understand the visual content that the user provides, "
+                     "and assist the user with a variety of tasks using natural language.")
 PAD_TAG = "<｜▁pad▁｜>"                                # processing_vlm.py:91
 GROUNDING_OPEN, GROUNDING_CLOSE = "<grounding>", "</grounding>"
 
@@ -54,6 +60,35 @@ def wrap_uni_prompt_text(caption: str, grounding: Optional[str], in_stage1: bool
     conv = [{"role": ROLES[0], "content": caption}, {"role": ROLES[1], "content": f"{grounding}"}]
     sft = apply_sft_template(conv)
     return sft if in_stage1 else sft + IMAGE_START_TAG
+
+
+def wrap_mmu_prompt_text(question: str, answer: str = "") -> str:
+    """System.wrap_mmu_prompt (plangen_base.py:263-290), text part: the user turn is ``<image_placeholder>\\n{question}``, the
+    assistant turn the (usually empty) answer, rendered by VLChatProcessor.process_one with ITS system prompt
+    (processing_vlm.py:290-296)."""
+    conv = [{"role": ROLES[0], "content": f"{IMAGE_TAG}\n{question}"}, {"role": ROLES[1], "content": f"{answer}"}]
+    return apply_sft_template(conv, MMU_SYSTEM_PROMPT)
+
+
+def expand_image_tokens(ids: Sequence[int], image_id: int, image_start_id: int, image_end_id: int, num_image_tokens: int) -> List[int]:
+    """VLChatProcessor.add_image_token (processing_vlm.py:210-262, add_special_token=False): every ``<image_placeholder>`` id is
+    REPLACED by ``<begin_of_image>`` + num_image_tokens x ``<image_placeholder>`` + ``<end_of_image>``; the placeholder slots are
+    what images_seq_mask marks (:379-380) and prepare_inputs_embeds overwrites with the aligner's output."""
+    out: List[int] = []
+    for t in ids:
+        if int(t) == image_id:
+            out += [image_start_id] + [image_id] * num_image_tokens + [image_end_id]
+        else:
+            out.append(int(t))
+    return out
+
+
+def wrap_mmu_prompt_ids(codec, question: str, num_image_tokens: int, answer: str = "") -> Tuple[str, List[int], List[bool]]:
+    """-> (prompt, input_ids with the image slots expanded, images_seq_mask)."""
+    prompt = wrap_mmu_prompt_text(question, answer)
+    img = codec.token_id(IMAGE_TAG)
+    ids = expand_image_tokens(codec.encode(prompt), img, codec.token_id(IMAGE_START_TAG), codec.token_id(IMAGE_END_TAG), num_image_tokens)
+    return prompt, ids, [t == img for t in ids]
 
 
 def wrap_uni_prompt_ids(codec, caption: str, grounding: Optional[str], in_stage1: bool = False) -> Tuple[str, List[int]]:
@@ -114,6 +149,13 @@ class HFCodec:
     def encode(self, text: str) -> List[int]:
         return self.tok.encode(text)                      # adds BOS like the reference's tokenizer.encode(prompt)
 
+    def token_id(self, tag: str) -> int:
+        """tokenizer.vocab.get(tag) (processing_vlm.py:102, :181-207 image_id / image_start_id / image_end_id)."""
+        i = self.tok.convert_tokens_to_ids(tag)
+        if i is None or i < 0 or i == self.tok.unk_token_id:
+            raise KeyError(f"tokenizer has no token {tag!r}")
+        return int(i)
+
     def decode(self, ids: Sequence[int]) -> str:
         return self.tok.decode(list(ids), skip_special_tokens=False)     # plangen_base.py:294
 
@@ -131,7 +173,7 @@ class TagWordCodec:
         self._t2i: Dict[str, int] = {SEP2: eos_id, PAD_TAG: pad_id}
         self._i2t: Dict[int, str] = {eos_id: SEP2, pad_id: PAD_TAG, bos_id: ""}
         self._next = first_id
-        for t in (ROLES[0], ROLES[1], IMAGE_START_TAG, IMAGE_TAG, GROUNDING_OPEN, GROUNDING_CLOSE, "<ref>", "</ref>", "<box>", "</box>",
+        for t in (ROLES[0], ROLES[1], IMAGE_START_TAG, IMAGE_TAG, IMAGE_END_TAG, GROUNDING_OPEN, GROUNDING_CLOSE, "<ref>", "</ref>", "<box>", "</box>",
                   " ", "\n\n", "\n", ":", ",", "[", "]", "."):
             self._add(t)
         for n in range(10):
@@ -149,6 +191,9 @@ class TagWordCodec:
 
     def encode(self, text: str) -> List[int]:
         return [self.bos_token_id] + [self._add(p) for p in self._PIECE.findall(text)]
+
+    def token_id(self, tag: str) -> int:
+        return self._add(tag)
 
     def decode(self, ids: Sequence[int]) -> str:
         return "".join(self._i2t.get(int(i), "") for i in ids)

@@ -72,7 +72,8 @@ class System(_HotPath):
         super().__init__(cfg, eng, SimpleNamespace(seed=args.seed, parallel_size=args.parallel_size, cfg_weight=args.cfg_weight,
                                                    temperature=args.temperature, use_teacher_forcing=args.use_teacher_forcing,
                                                    debug_max_seq_len=args.debug_max_seq_len, janus_hw=args.janus_hw,
-                                                   neg_prompt=getattr(args, "neg_prompt", "")), codec=codec)
+                                                   neg_prompt=getattr(args, "neg_prompt", ""),
+                                                   use_neg_box=bool(getattr(args, "use_neg_box", False))), codec=codec)
         self.cli = args
         self.accelerator = accelerator
         self.max_new_tokens = text_new
@@ -116,6 +117,12 @@ class System(_HotPath):
             s1 = None
         if s1 is not None:
             b["uni_stage1_inputs_ids"], b["uni_stage1_attention_mask"] = self.pad_input_ids(s1)
+        if all("neg_base_caption" in r for r in rows):                  # use_neg_box rows (plangen_base.py:652-670)
+            b["neg_base_caption"] = [r["neg_base_caption"] for r in rows]
+            b["neg_gt_grounding"] = [r.get("neg_gt_grounding", "") for r in rows]
+        for key, col in (("image", "image_pt"), ("edited_image", "edited_image_pt")):     # [3,S,S] tensors in [-1,1] saved with torch.save
+            if all(col in r for r in rows):
+                b[key] = torch.stack([torch.load(r[col]).float() for r in rows])
         negs = [r["neg_ids"] for r in rows if "neg_ids" in r]
         if len(negs) == len(rows):
             b["neg_inputs_ids"] = negs[0] if all(n == negs[0] for n in negs) else negs
@@ -126,37 +133,51 @@ class System(_HotPath):
         return b
 
     def _mmu_inputs(self, rows):
-        """wrap_mmu_prompt's tensors (plangen_base.py:263-290) for synthetic / pre-tokenised rows: one image per sample,
-        ``<image_placeholder>`` expanded to vit_tokens slots (processing_vlm.py add_image_token), left-padded."""
+        """wrap_mmu_prompt's tensors (plangen_base.py:263-290), one image per sample, left-padded (processing_vlm.py batchify).
+        With a tokenizer the text goes through the reference's conversation -- ``<|User|>: <image_placeholder>\\n{question}`` /
+        empty assistant turn under VLChatProcessor's system prompt -- and the placeholder id is expanded to
+        ``<begin_of_image>`` + vit_tokens slots + ``<end_of_image>`` (add_image_token, processing_vlm.py:243-248).
+        Rows with ``question_ids`` (pre-tokenised) keep the bare form [first id] + slots + [rest]."""
+        from plangen_amd.textproc import wrap_mmu_prompt_ids
         cfg = self.cfg
         P = cfg.vit_tokens
         g = torch.Generator().manual_seed(self.cli.seed + 17)
         seqs = []
         for r in rows:
-            q = r.get("question_ids") or self._codec().encode(r.get("base_caption", ""))[:32]
-            seqs.append([q[0]] + [-1] * P + list(q[1:]))             # -1 = image slot (replaced by embeddings)
-        L = max(map(len, seqs))
+            if r.get("question_ids"):
+                q = r["question_ids"]
+                seqs.append(([q[0]] + [0] * P + list(q[1:]), [False] + [True] * P + [False] * (len(q) - 1)))
+            else:
+                _, ids, slot = wrap_mmu_prompt_ids(self._codec(), r.get("question", r.get("base_caption", "")), P)
+                seqs.append((ids, slot))
+        L = max(len(s[0]) for s in seqs)
         ids = torch.full((len(rows), L), cfg.pad_id, dtype=torch.long)
         seq_mask = torch.zeros((len(rows), L), dtype=torch.bool)
         attn = torch.zeros((len(rows), L), dtype=torch.int32)
-        for i, s in enumerate(seqs):
-            t = torch.tensor(s)
-            ids[i, L - len(s):] = t
-            seq_mask[i, L - len(s):] = t < 0
-            attn[i, L - len(s):] = 1
+        for i, (s_ids, slot) in enumerate(seqs):
+            n = len(s_ids)
+            ids[i, L - n:] = torch.tensor(s_ids)
+            seq_mask[i, L - n:] = torch.tensor(slot)
+            attn[i, L - n:] = 1
         pix = torch.stack([torch.load(r["image_pt"]) if "image_pt" in r else torch.rand(3, cfg.vit_img, cfg.vit_img, generator=g) * 2 - 1
                            for r in rows])[:, None]
         return dict(input_ids=ids, pixel_values=pix, images_seq_mask=seq_mask, images_emb_mask=torch.ones((len(rows), 1, P), dtype=torch.bool),
                     attention_mask=attn)
 
     def setup_data(self, accelerator=None):
+        """Prompt sharding (plangen_base.py:994) over WHOLE batches: rank r owns a contiguous run of test batches, so its first
+        row sits on a multiple of test_batch_size and the reference's file names ``{idx*bs+i}`` (:1171-1176), computed with the
+        GLOBAL batch index, are the global row index -- no two ranks can write the same file (sharding rows gave
+        64 rows / 3 ranks / bs 8 colliding names)."""
         a = self.cli
         rank, ws = world()
         rows = self._rows()
-        lo, hi = shard_range(len(rows), ws, rank)                    # prompt sharding (plangen_base.py:994)
-        self.row_offset = lo
-        rows = rows[lo:hi]
-        bs = a.test_batch_size
+        bs = int(a.test_batch_size)
+        nb = (len(rows) + bs - 1) // bs
+        lo, hi = shard_range(nb, ws, rank)
+        self.batch_offset = lo
+        self.row_offset = lo * bs
+        rows = rows[lo * bs:hi * bs]
         self.test_dataloader = [self.collate(rows[i:i + bs]) for i in range(0, len(rows), bs)]
         return self.test_dataloader
 
@@ -167,8 +188,10 @@ class System(_HotPath):
         resume path is an error, not a silent random-weight run."""
         a = self.cli
         ck = latest_checkpoint(a.out_path) if a.resume == "latest" else a.resume
-        if a.resume not in (None, "latest") and not os.path.exists(str(a.resume)):
-            raise FileNotFoundError(f"resume={a.resume!r} does not exist")
+        if isinstance(ck, int) or (isinstance(ck, str) and ck.isdigit()):      # base_system.py:132-134: resume=<int> -> out_path/checkpoint-<int>
+            ck = os.path.join(a.out_path, f"checkpoint-{int(ck)}")
+        if a.resume not in (None, "latest") and not os.path.exists(str(ck)):
+            raise FileNotFoundError(f"resume={a.resume!r}: {ck!r} does not exist")
         if a.janus_path and os.path.isdir(str(a.janus_path)):
             info = load_checkpoint(self.engine, a.janus_path, overlay=ck, strict=True)
             print(f"loaded {info['loaded'][0]} tensors from {a.janus_path}" + (f" + overlay {ck}" if ck else "")
@@ -219,10 +242,11 @@ class System(_HotPath):
                 break
             if idx < int(getattr(a, "test_start", 0)):
                 continue
-            gidx = self.row_offset // bs0 + idx if ws > 1 else idx          # global batch index: ranks do not overwrite each other
+            gidx = getattr(self, "batch_offset", 0) + idx                  # GLOBAL batch index (whole batches are sharded): names == a single-rank run's
             out = self.uni_generate(batch=batch, batch_idx=f"{gidx}", gen_path=batch_path, save_local=True, max_new_tokens=self.max_new_tokens,
                                     **kwargs)
             pr_image, gt_image, image_id = out.get("pr_image"), batch.get("image"), batch["image_id"]
+            edited_image = batch.get("edited_image")
             layouts.append(out.get("pr_grounding"))
             bs = len(image_id)
             p = int(a.parallel_size)
@@ -240,4 +264,7 @@ class System(_HotPath):
                     n_img += 1
                 if gt_image is not None:
                     save_image(gt_image[i], f"{path}/gt_image/{gidx * bs0 + i}.png")
+                if edited_image is not None:                                   # plangen_base.py:1179-1181
+                    os.makedirs(f"{path}/edited_image", exist_ok=True)
+                    save_image(edited_image[i], f"{path}/edited_image/{gidx * bs0 + i}.png")
         return {"task_type": task, "images": n_img, "batches": len(layouts), "out_dir": path, "batch_dir": batch_path}

@@ -81,3 +81,22 @@ def test_bench_refuses_mislabelled_world_size():
     rc, out, err = _bench("--gpus", "4", "--launch-check", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0",
                                                                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     assert rc != 0 and out is None and "WORLD_SIZE" in err
+
+
+def test_bench_launcher_config4_dry_run():
+    """BASELINE configs[3]: 256 images over 8 ranks (32 per rank) through the launcher's own spawn path (gloo dry run)."""
+    rc, out, err = _bench("--gpus", "8", "--launch-check", "--global-batch", "256")
+    assert rc == 0, err
+    assert out == {"launch_check": "ok", "world": 8, "global_images": 256, "images_rank0": 32, "backend": "gloo"}
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """Rank 1 exits before the first collective: the launcher must notice (it polls every child), terminate the surviving
+    ranks -- which would otherwise sit in the all-reduce until the collective timeout -- and return non-zero promptly."""
+    import time
+    t0 = time.time()
+    rc, out, err = _bench("--gpus", "3", "--launch-check", "--batch", "2", env={"PG_TEST_DIE_RANK": "1", "PG_DIST_TIMEOUT_S": "120"})
+    dt = time.time() - t0
+    assert rc != 0 and out is None
+    assert "rank 1 exited with rc 7" in err and "terminating the other ranks" in err, err
+    assert dt < 60, dt                                     # far below the 120 s collective timeout

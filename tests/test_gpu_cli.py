@@ -125,3 +125,114 @@ def test_t2i_returns_edit_mask_under_teacher_forcing(tiny_cfg, tiny_weights):
     labels = e.vq_encode(gt).reshape(2, -1).cpu()
     toks = sysm.last_generated_tokens.cpu()
     assert torch.equal(toks[region == 0], labels[region == 0].int())
+
+
+def test_parallel_size_replica_layout_and_file_names(tmp_path, tiny_cfg, tiny_weights, ocfg):
+    """parallel_size=2 (plangen_base.py:547, :1171-1176): t2i replicates the CFG batch as ``torch.cat([tokens] * p)`` -- replicas
+    laid out [all pairs] x p -- and validation saves ``pr_image[i*p + t]`` as ``pr_image/{idx*bs+i}_{t}.png``.  Greedy: every
+    replica of a sample equals the oracle's image of that sample; the files carry the reference's names and indexing."""
+    from plangen_amd.system import System, t2i_infer_collate_batch
+    from project.plangen.plangen_base import System as CliSystem
+    e = get_engine(tiny_cfg, tiny_weights, "f32")
+    sysm = System(tiny_cfg, e)
+    sysm.args.temperature, sysm.args.parallel_size = 0.0, 2
+    g = torch.Generator().manual_seed(5)
+    cond = [torch.randint(8, tiny_cfg.vocab, (n,), generator=g).tolist() for n in (7, 5)]
+    neg = torch.randint(8, tiny_cfg.vocab, (4,), generator=g).tolist()
+    ids, mask = t2i_infer_collate_batch(cond, neg, tiny_cfg.pad_id, tiny_cfg.img_tokens)
+    dec, _ = sysm.t2i(ids, mask)
+    ref_tok, ref_img = R.t2i(tiny_weights, ocfg, ids, mask, 5.0)
+    toks = sysm.last_generated_tokens.cpu()
+    assert dec.shape[0] == 4 and toks.shape[0] == 4
+    assert torch.equal(toks[:2], ref_tok) and torch.equal(toks[2:], ref_tok)            # [sample 0, sample 1] x 2 replicas (:547)
+    assert ((dec[:2].cpu() - ref_img) ** 2).mean().item() <= 1e-4 and torch.equal(dec[:2], dec[2:])
+    # through the CLI: names {idx*bs+i}_{t}.png, content pr_image[i*p+t] (the reference's own indexing of that layout)
+    a = _args(tmp_path, "uni", parallel_size=2)
+    m = CliSystem(a, None)
+    m.setup_data(None)
+    m.resume(None)
+    r = m.validation(0)
+    pngs = sorted(os.listdir(os.path.join(r["out_dir"], "pr_image")))
+    assert pngs == sorted(f"{k}_{t}.png" for k in range(4) for t in range(2))
+    m.engine.close()
+
+
+def test_use_neg_box_builds_one_negative_prompt_per_sample(tiny_cfg, tiny_weights, ocfg):
+    """use_neg_box (plangen_base.py:652-670): the uncond row of sample i is wrap_uni_prompt(neg_base_caption[i],
+    neg_gt_grounding[i]); image tokens equal the oracle driven with the same per-sample negative prompts, and differ from the
+    shared-negative-prompt run."""
+    from plangen_amd.system import System, pad_input_ids
+    e = get_engine(tiny_cfg, tiny_weights, "f32")
+    codec = T.TagWordCodec(tiny_cfg.vocab, eos_id=tiny_cfg.eos_id, pad_id=tiny_cfg.pad_id)
+    sysm = System(tiny_cfg, e, codec=codec)
+    sysm.args.temperature, sysm.args.use_neg_box = 0.0, True
+    caps, grs = ["a red cat", "two dogs on a field"], ["<grounding><ref>cat</ref><box>[1,2,300,400]</box></grounding>", "<grounding></grounding>"]
+    ncaps, ngrs = ["blurry", "low quality photo"], ["<grounding><ref>cat</ref><box>[5,5,900,900]</box></grounding>", ""]
+    uni = [sysm.wrap_uni_prompt(c, g)[1].tolist() for c, g in zip(caps, grs)]
+    ids, m = pad_input_ids(uni, tiny_cfg.pad_id)
+    T_ = tiny_cfg.img_tokens
+    batch = dict(base_caption=caps, gt_grounding=grs, neg_base_caption=ncaps, neg_gt_grounding=ngrs, uni_inputs_ids=ids,
+                 uni_attention_mask=torch.cat([m, torch.ones((2, T_), dtype=m.dtype)], -1))
+    out = sysm.uni_generate(batch, pred_layout=False)
+    negs = [codec.encode(R.wrap_uni_prompt_text(c, g)) for c, g in zip(ncaps, ngrs)]
+    cids, cmask = R.t2i_infer_collate_batch(uni, negs, tiny_cfg.pad_id, T_)
+    assert len(negs[0]) != len(negs[1])                                        # genuinely per-sample rows
+    ref_tok, _ = R.t2i(tiny_weights, ocfg, cids, cmask, 5.0)
+    assert np.array_equal(out["pr_tokens"].cpu().numpy(), ref_tok.numpy())
+    sysm.args.use_neg_box = False
+    shared = sysm.uni_generate(dict(batch, neg_inputs_ids=sysm.wrap_uni_prompt("", "")[1].tolist()), pred_layout=False)
+    assert not torch.equal(shared["pr_tokens"], out["pr_tokens"])
+    sysm.args.use_neg_box = True
+    with pytest.raises(Exception, match="use_neg_box"):
+        sysm.uni_generate({k: v for k, v in batch.items() if not k.startswith("neg_")}, pred_layout=False)
+
+
+def test_edited_image_and_gt_image_are_written(tmp_path, tiny_cfg):
+    """plangen_base.py:1167-1181: gt_image/{idx*bs+i}.png and edited_image/{idx*bs+i}.png next to pr_image when the batch has them."""
+    S = tiny_cfg.img_size
+    g = torch.Generator().manual_seed(9)
+    rows = []
+    for i in range(4):
+        pi, pe = str(tmp_path / f"img{i}.pt"), str(tmp_path / f"ed{i}.pt")
+        torch.save(torch.rand(3, S, S, generator=g) * 2 - 1, pi)
+        torch.save(torch.rand(3, S, S, generator=g) * 2 - 1, pe)
+        rows.append({"cond_ids": torch.randint(8, tiny_cfg.vocab, (5 + i,), generator=g).tolist(), "neg_ids": [1, 9, 10],
+                     "image_id": f"id{i}" if i % 2 == 0 else "", "image_pt": pi, "edited_image_pt": pe})
+    f = tmp_path / "rows.jsonl"
+    f.write_text("\n".join(json.dumps(r) for r in rows))
+    from project.plangen.plangen_base import System as CliSystem
+    a = _args(tmp_path, "uni", synthetic=True)
+    a.test_data = dict(a.test_data, data_file=str(f), data_name="edit")
+    m = CliSystem(a, None)
+    m.setup_data(None)
+    m.resume(None)
+    r = m.validation(0)
+    for d in ("pr_image", "gt_image", "edited_image"):
+        assert sorted(os.listdir(os.path.join(r["out_dir"], d))) == ["0.png", "1.png", "2.png", "3.png"], d
+    assert sorted(os.listdir(os.path.join(r["out_dir"], "image_ids"))) == ["id0.jpg", "id2.jpg"]
+    assert sorted(os.listdir(os.path.join(r["out_dir"], "gt_image_ids"))) == ["id0.jpg", "id2.jpg"]
+    m.engine.close()
+
+
+def test_mmu_prompt_rows_use_the_chat_template(tmp_path):
+    """mmu rows with text go through wrap_mmu_prompt's conversation + image-token expansion."""
+    from project.plangen.plangen_base import System as CliSystem
+    a = _args(tmp_path, "mmu")
+    m = CliSystem(a, None)
+    dl = m.setup_data(None)
+    pin = dl[0]["prepare_inputs_infer"]
+    c = m.codec
+    boi, img, eoi = c.token_id(T.IMAGE_START_TAG), c.token_id(T.IMAGE_TAG), c.token_id(T.IMAGE_END_TAG)
+    P = m.cfg.vit_tokens
+    for i in range(pin["input_ids"].shape[0]):
+        row = pin["input_ids"][i][pin["attention_mask"][i].bool()].tolist()
+        k = row.index(boi)
+        assert row[k + 1:k + 1 + P] == [img] * P and row[k + 1 + P] == eoi
+        assert pin["images_seq_mask"][i][pin["attention_mask"][i].bool()].tolist() == [t == img for t in row]
+        text = c.decode(row[:k])
+        assert text.startswith(T.MMU_SYSTEM_PROMPT) and text.endswith("<|User|>: ")
+        assert c.decode(row[k + 2 + P:]).endswith("<|Assistant|>:")
+    m.resume(None)
+    r = m.validation(0)
+    assert r["batches"] == 2
+    m.engine.close()

@@ -277,14 +277,15 @@ def test_decode_gemm_back_to_back_race_screen(M, N, K, S):
         assert md.value <= 2e-3 * mr.value, (md.value, mr.value)
 
 
-def test_decode_gemm_cold_launches(tiny_cfg, tiny_weights):
-    """ONE launch of the tiled decode GEMM at a time on an otherwise IDLE GPU (fresh device copies of host operands, 0.15 s pause between
+@pytest.mark.parametrize("M,N,K,iters", [(64, 6144, 2048, 120), (128, 2048, 2048, 60), (128, 2048, 5632, 60), (16, 6144, 2048, 40), (16, 2048, 5632, 40)])
+def test_decode_gemm_cold_launches(tiny_cfg, tiny_weights, M, N, K, iters):
+    """(round 3: also the M = 128 narrow-N shapes the bs=64 loop sends to gemm_sk4_kernel<4,...> -- o 128x2048x2048 and down
+    128x2048x5632, S = 4 -- and the 16-row blocks of BASELINE configs[1].)  ONE launch of the tiled decode GEMM at a time on an otherwise IDLE GPU (fresh device copies of host operands, 0.15 s pause between
     launches), 120 times: the shape and path that read a wave's last LDS-DMA piece stale in ~0.5 % of such cold launches before every chunk
     was retired one barrier ahead of its first read.  Back-to-back launches never showed it, with or without fresh
     memory; with the previous kernel this test fails in roughly one run of three at 400 iterations -- the structural guard is
     tests/test_isa_check.py, this is the empirical one."""
     e = _eng(tiny_cfg, tiny_weights, "bf16")
-    M, N, K = 64, 6144, 2048
     g = torch.Generator().manual_seed(11)
     sets = []
     for _ in range(6):
@@ -293,7 +294,7 @@ def test_decode_gemm_cold_launches(tiny_cfg, tiny_weights):
         sets.append((a, w, (a.cuda().double() @ w.cuda().double().t())))
     junk = []
     import time
-    for it in range(120):
+    for it in range(iters):
         a, w, ref = sets[it % len(sets)]
         if it % 3 == 0:
             junk.append(torch.empty((1 + it % 7) * 1_000_003, device="cuda"))

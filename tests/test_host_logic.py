@@ -58,6 +58,11 @@ def test_per_sample_negative_prompts():
     assert ids.shape == (4, 5)
     assert ids[1].tolist() == [0, 0, 0, 1, 2] and ids[3].tolist() == [3, 4, 5, 6, 7]
     assert mask[0].tolist() == [0, 1, 1, 1, 1, 1, 1, 1, 1]
+    rid, rmask = R.t2i_infer_collate_batch(cond, negs, 0, 4)               # the oracle's use_neg_box branch (plangen_base.py:652-670)
+    assert torch.equal(ids, rid) and torch.equal(mask, rmask)
+    cond2 = [[5, 6, 7, 8, 9, 10, 11], [9, 10]]                             # cond longer than every negative prompt
+    a, b = t2i_infer_collate_batch(cond2, negs, 0, 4), R.t2i_infer_collate_batch(cond2, negs, 0, 4)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[0].shape == (4, 7)
 
 
 def test_pad_len_from_mask():

@@ -1,8 +1,10 @@
-"""CPU: the v4 decode GEMM's hand-counted `s_waitcnt vmcnt(N)` and its LDS ring discipline, checked against the code hipcc
-actually emits for gfx950 (tools/sk4_isa_check.py walks `hipcc -S` output of gemm.hip: every barrier is preceded by a wait that
-retires the chunk's x DMA pieces, every MFMA reads W fragments from retired loads, every x fragment read sits between the barrier
-of its chunk and the next).  A compiler that reorders a load across one of the counted waits -- what caused the round-2 cold-launch
-failure -- fails here without a GPU."""
+"""CPU: the LDS-DMA staging protocols of every global_load_lds kernel, checked against the code hipcc actually emits for gfx950.
+
+tools/dma_isa_check.py replays each kernel's instruction stream (VMEM operations retire in issue order): the prefill flash
+attention, the 256x256 GEMM and the halo convolution's weight ring must retire a staged tile ONE BARRIER BEFORE the phase that
+reads it and re-stage a slot only behind a barrier that follows its last read; tools/sk4_isa_check.py (called from it) walks the
+114 decode-GEMM instantiations with their hand-counted `s_waitcnt vmcnt(N)`.  A compiler that reorders a load across a counted
+wait -- what caused the round-2 cold-launch failure -- or a new LDS-DMA kernel without a protocol spec fails here without a GPU."""
 import os
 import shutil
 import subprocess
@@ -14,8 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="hipcc not available")
-def test_sk4_counted_waits_match_the_compiled_code(tmp_path):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sk4_isa_check.py")], capture_output=True, text=True, timeout=900)
+def test_lds_dma_protocols_match_the_compiled_code():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dma_isa_check.py")], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
-    assert "0 failed" in p.stdout and "instantiations checked" in p.stdout
-    assert int(p.stdout.strip().split()[0]) >= 40           # production + bench instantiations
+    out = p.stdout
+    assert out.strip().endswith("0 failed")
+    assert out.count("fifo protocol holds in the strict form") >= 3           # flash2 + two gemm256 instantiations
+    assert out.count("weight ring strict") == 2                               # production halo convolution (plain + upsample)
+    sk4 = [l for l in out.splitlines() if l.startswith("sk4:")][0]
+    assert "0 failed" in sk4 and int(sk4.split()[1]) >= 40                    # production + bench instantiations of the decode GEMM

@@ -17,6 +17,8 @@ def test_chat_template_matches_reference_conversation_py():
     cases = json.load(open(os.path.join(GOLDEN, "text_golden.json")))
     assert len(cases) >= 5
     for c in cases:
+        if "mmu_question" in c:
+            continue
         assert T.wrap_uni_prompt_text(c["caption"], c["grounding"], c["in_stage1"]) == c["prompt"], c
     assert T.wrap_t2i_prompt_text("two dogs playing") == "<|User|>: two dogs playing\n\n<|Assistant|>:<begin_of_image>"
 
@@ -88,4 +90,60 @@ def test_cli_resume_errors_are_loud(tmp_path):
         s.resume()
     s.cli.resume = None
     with pytest.raises(FileNotFoundError, match="janus_path"):
+        s.resume()
+
+
+def test_mmu_chat_template_matches_reference_conversation_py():
+    """wrap_mmu_prompt's text (plangen_base.py:263-279) as VLChatProcessor renders it -- the reference's conversation.py under the
+    processor's own system prompt (fixture: oracle/make_golden.py::golden_text); ADVICE r2: mmu prompts were bare caption tokens."""
+    cases = [c for c in json.load(open(os.path.join(GOLDEN, "text_golden.json"))) if "mmu_question" in c]
+    assert len(cases) >= 3
+    for c in cases:
+        assert T.wrap_mmu_prompt_text(c["mmu_question"], c["mmu_answer"]) == c["prompt"], c
+    assert cases[0]["prompt"].startswith("You are a helpful language and vision assistant.") and cases[0]["prompt"].endswith("<|Assistant|>:")
+    assert "<|User|>: <image_placeholder>\nDescribe the layout of the image.\n\n<|Assistant|>:" in cases[0]["prompt"]
+
+
+def test_image_placeholder_expansion_like_add_image_token():
+    """processing_vlm.py:243-248 (add_special_token=False): the placeholder id is replaced by boi + P slots + eoi."""
+    assert T.expand_image_tokens([1, 5, 9, 6], image_id=9, image_start_id=20, image_end_id=21, num_image_tokens=3) == [1, 5, 20, 9, 9, 9, 21, 6]
+    assert T.expand_image_tokens([9, 9], 9, 20, 21, 1) == [20, 9, 21, 20, 9, 21]
+    c = T.TagWordCodec(512)
+    prompt, ids, slots = T.wrap_mmu_prompt_ids(c, "what is there?", 4)
+    img, boi, eoi = c.token_id(T.IMAGE_TAG), c.token_id(T.IMAGE_START_TAG), c.token_id(T.IMAGE_END_TAG)
+    k = ids.index(boi)
+    assert ids[k:k + 6] == [boi, img, img, img, img, eoi] and sum(slots) == 4 and slots[k + 1:k + 5] == [True] * 4
+    assert c.decode(ids[:k]).endswith("<|User|>: ") and c.decode(ids[k + 6:]).startswith("\nwhat is there?")
+
+
+def test_cli_shards_whole_batches_so_file_names_cannot_collide(monkeypatch):
+    """64 rows over 3 ranks with test_batch_size 8 -- every rank starts on a batch boundary, the global batch indices
+    partition 0..7, and the names {gidx*bs+i} of all ranks are exactly 0..63."""
+    from project.plangen import plangen_base as P
+    names = []
+    for rank in range(3):
+        s = object.__new__(P.System)
+        s.cli = SimpleNamespace(test_batch_size=8)
+        s._rows = lambda: [{"k": i} for i in range(64)]
+        s.collate = lambda rows: rows
+        monkeypatch.setattr(P, "world", lambda r=rank: (r, 3))
+        dl = s.setup_data()
+        assert s.row_offset == s.batch_offset * 8
+        for idx, b in enumerate(dl):
+            names += [(s.batch_offset + idx) * 8 + i for i in range(len(b))]
+            assert [r["k"] for r in b] == list(range((s.batch_offset + idx) * 8, (s.batch_offset + idx) * 8 + len(b)))
+    assert sorted(names) == list(range(64)) and len(set(names)) == 64
+
+
+def test_cli_integer_resume_maps_to_checkpoint_dir(tmp_path):
+    """base_system.py:132-134: resume=<int> -> out_path/checkpoint-<int>."""
+    from project.plangen.plangen_base import System
+    s = object.__new__(System)
+    s.engine = None
+    s.synthetic = False
+    s.cli = SimpleNamespace(out_path=str(tmp_path), resume=7, janus_path=str(tmp_path / "nope"))
+    with pytest.raises(FileNotFoundError, match="checkpoint-7"):
+        s.resume()
+    os.makedirs(tmp_path / "checkpoint-7")
+    with pytest.raises(FileNotFoundError, match="janus_path"):          # the overlay resolves; the base weights are what is missing now
         s.resume()

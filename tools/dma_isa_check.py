@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Static check of the LDS-DMA (global_load_lds) staging protocols against the code hipcc EMITS for gfx950.
+
+Rule being checked (CDNA guide; the same-phase form of the decode GEMM read a stale DMA piece in ~0.5 % of cold launches,
+DESIGN 4.1): a staged tile is RETIRED -- the issuing wave's `s_waitcnt vmcnt(N)` followed by a block barrier -- one barrier
+BEFORE the phase that first reads it, never in the phase its retiring barrier opens; and a ring slot is re-staged only after
+a barrier that follows its last read.
+
+VMEM operations retire in issue order (tools/dma_order_probe.py), so a kernel's protocol can be replayed from the instruction
+stream alone: walk prologue + R copies of the main loop, number the global_load_lds instructions, and at every
+`s_waitcnt vmcnt(N)` mark all but the N youngest VMEM operations retired.  Every kernel that contains a global_load_lds must
+have a spec below (a new LDS-DMA kernel without one fails the check):
+
+  fifo    tiles are consumed in the order they were issued; the spec names which LDS-read instruction class consumes which
+          tile of the stream in loop iteration i.  Checked per read: the tile was retired as of the barrier BEFORE the most
+          recent one (strict form), and per DMA: the tile that last lived in its slot was read before an earlier barrier.
+  sk4     gemm_sk4_kernel: tools/sk4_isa_check.py (own walker: W register ring + x ring share one vmcnt counter).
+  legacy  same-phase protocol kept knowingly (listed with the reason); only the weak form is checked: wait -> barrier -> read.
+
+usage: dma_isa_check.py            (compiles plangen_amd/csrc/*.hip with -S into /tmp/dma_isa/)"""
+import os, re, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "plangen_amd", "csrc")
+OUT = "/tmp/dma_isa"
+
+
+def compile_s(name):
+    os.makedirs(OUT, exist_ok=True)
+    src, dst = os.path.join(CSRC, name + ".hip"), os.path.join(OUT, name + ".s")
+    deps = [src] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    if not os.path.exists(dst) or any(os.path.getmtime(d) > os.path.getmtime(dst) for d in deps):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                               src, "-I", CSRC, "-o", dst], stderr=subprocess.DEVNULL)
+    return open(dst).read().splitlines()
+
+
+def functions(lines):
+    """name -> list of (kind, payload) events in program order; labels and branches kept for loop detection."""
+    out, i = {}, 0
+    while i < len(lines):
+        m = re.match(r"^(_Z\w+):\s*; @", lines[i])
+        if not m:
+            i += 1
+            continue
+        name, ev, j = m.group(1), [], i + 1
+        while j < len(lines) and "s_endpgm" not in lines[j]:
+            t = lines[j].strip()
+            if re.match(r"^\.LBB\d+_\d+:", t): ev.append(("label", t.split(":")[0]))
+            elif t.startswith(("s_cbranch", "s_branch")): ev.append(("branch", t.split()[-1]))
+            elif t.startswith("global_load_lds") or (t.startswith("buffer_load") and " lds" in t): ev.append(("dma", None))
+            elif t.startswith(("global_load", "buffer_load", "global_store", "buffer_store", "global_atomic", "flat_load", "flat_store")): ev.append(("vmem", None))
+            elif t.startswith("s_waitcnt") and "vmcnt(" in t: ev.append(("wait", int(re.search(r"vmcnt\((\d+)\)", t).group(1))))
+            elif t.startswith("s_barrier"): ev.append(("bar", None))
+            elif t.startswith("ds_read"): ev.append(("read", t.split()[0]))
+            j += 1
+        out[name] = ev
+        i = j
+    return out
+
+
+def main_loop(ev):
+    """(prologue, body): the innermost backward-branch loop that contains both DMA issues and LDS reads."""
+    pos = {p: k for k, (kind, p) in enumerate(ev) if kind == "label"}
+    best = None
+    for k, (kind, p) in enumerate(ev):
+        if kind == "branch" and p in pos and pos[p] < k:
+            body = ev[pos[p]:k]
+            if any(e[0] == "dma" for e in body) and any(e[0] == "read" for e in body):
+                if best is None or len(body) < best[1] - best[0]:
+                    best = (pos[p], k)
+    if best is None:
+        return None, None
+    return ev[:best[0]], ev[best[0]:best[1]]
+
+
+def replay(prologue, body, spec, R=6):
+    """Replays prologue + R x body.  spec: g (DMA instructions per tile per wave), need(i, cls) -> tile index consumed by read
+    class cls in iteration i (None: not a staged read), slot_reuse (a tile's slot is reused by tile + slot_reuse(cls-of-tile)),
+    tile_cls(n) -> class of stream tile n, strict (tile retired one barrier early) else weak."""
+    g = spec["g"]
+    issued = retired = dma_n = 0
+    bars = 0
+    snap = [0]                      # snap[b] = VMEM ops retired when barrier b (1-based) was passed
+    dma_index = []                  # VMEM issue index of every DMA instruction
+    last_read_bar = {}              # tile -> number of barriers passed at its last read
+    errs = []
+    stream = [("p", e) for e in prologue]
+    for i in range(R):
+        stream += [(i, e) for e in body]
+    pend_wait = None
+    for it, (kind, val) in stream:
+        if kind == "wait":
+            pend_wait = val if pend_wait is None else max(pend_wait, val)       # waits in exclusive tail branches: weakest one
+            continue
+        if pend_wait is not None and kind in ("dma", "vmem", "bar", "read"):
+            retired = max(retired, issued - pend_wait)
+            pend_wait = None
+        if kind in ("dma", "vmem"):
+            issued += 1
+            if kind == "dma":
+                tile = dma_n // g
+                dma_n += 1
+                dma_index.append(issued)
+                prev = tile - spec["slot_reuse"](spec["tile_cls"](tile))
+                if prev >= 0 and prev in last_read_bar and not (bars > last_read_bar[prev]):
+                    errs.append(f"iteration {it}: tile {tile} staged into the slot of tile {prev} with no barrier since that tile's last read")
+        elif kind == "bar":
+            bars += 1
+            snap.append(retired)
+        elif kind == "read" and it != "p":
+            tile = spec["need"](it, val)
+            if tile is None:
+                continue
+            last = (tile + 1) * g
+            if last > len(dma_index):
+                errs.append(f"iteration {it}: {val} needs tile {tile} which was never issued"); continue
+            need_ops = dma_index[last - 1]
+            back = 1 if spec.get("strict", True) else 0
+            if bars - back < 1 or snap[bars - back] < need_ops:
+                errs.append(f"iteration {it}: {val} reads tile {tile} (VMEM op #{need_ops}) but only {snap[max(bars - back, 0)]} ops were retired "
+                            f"{'one barrier before' if back else 'at'} the barrier that opens this phase")
+            last_read_bar[tile] = bars
+    return errs, dma_n
+
+
+# ---- specs -------------------------------------------------------------------------------------------------------------------
+def flash2_need(i, cls):
+    # stream: K0 V0 K1 | V(i+1) K(i+2) per iteration; QK^T reads (ds_read_b128) consume K(i), PV transpose reads consume V(i)
+    if cls == "ds_read_b128": return 2 * i
+    if cls == "ds_read_b64_tr_b16": return 2 * i + 1
+    return None
+
+
+def gemm256_need_factory():
+    # stream per K tile: HA0 HB0 HB1 HA1; phase 1 reads HA0 + HB0 (12 ds_read_b128), phase 2 HB1 (4), phase 3 HA1 (8)
+    state = {"i": -1, "n": 0}
+
+    def need(i, cls):
+        if cls != "ds_read_b128": return None
+        if state["i"] != i: state.update(i=i, n=0)
+        n = state["n"]; state["n"] += 1
+        if n < 8: return 4 * i              # HA0
+        if n < 12: return 4 * i + 1         # HB0
+        if n < 16: return 4 * i + 2         # HB1
+        return 4 * i + 3                    # HA1
+    return need
+
+
+SPECS = [
+    ("attn_prefill", r"attn_prefill_flash2_kernel", dict(kind="fifo", g=4, need=flash2_need, tile_cls=lambda n: n & 1, slot_reuse=lambda c: 4, strict=True,
+                                                         why="two barriers per tile: A(t) retires V(t), B(t) retires K(t+1)")),
+    ("gemm256", r"gemm256_kernel", dict(kind="fifo", g=2, need=None, tile_cls=lambda n: n & 3, slot_reuse=lambda c: 8, strict=True,
+                                        why="half-tiles retired by vmcnt(8) in the phase before they are read; two barriers per phase")),
+    ("gemm", r"gemm_sk4_kernel", dict(kind="sk4")),
+    ("gemm", r"gemm_big_kernel", dict(kind="legacy", why="128x128 double buffer: vmcnt(0) + __syncthreads, next tile read in the phase that barrier opens; "
+                                      "a third slot would halve its residency (96 KiB).  Not on the bench path's dominant shapes; cold-stressed "
+                                      "(tools/op_cold_stress.py, tests/test_gpu_ops.py cold tests)")),
+    ("conv_halo", r"conv3x3_halo_kernelI.*Lb1ELb[01]E", dict(kind="halo_stag", why="production: 4-slot weight ring, W(t+1) retired by vmcnt(2) in phase t and read in phase t+1; "
+                                                             "halo + W(0) retired two barriers before the first read")),
+    ("conv_halo", r"conv3x3_halo_kernelI.*Lb0ELb[01]E", dict(kind="legacy", why="conv_halo=2 option (not the default): vmcnt(4) + barrier, tile read in the phase that barrier opens")),
+    ("bench_kernels", r"dma_order_kernel", dict(kind="probe", why="measurement probe (tools/dma_order_probe.py), not on the product path")),
+    ("conv_halo", r"conv3x3_out_halo_kernel", dict(kind="once", why="halo patch staged once per tile: vmcnt(0) + barrier, then a second barrier-separated phase reads it")),
+]
+
+
+def check_weak(ev):
+    """legacy / fallback: every LDS read that follows a DMA issue has a vmcnt wait AND a barrier between the youngest DMA issued
+    before that wait and itself (wait -> barrier -> read)."""
+    state = 0           # 0: no un-waited DMA; 1: DMA outstanding; 2: waited, no barrier yet
+    for kind, val in ev:
+        if kind == "dma": state = 1
+        elif kind == "wait" and state == 1 and val == 0: state = 2
+        elif kind == "bar" and state == 2: state = 0
+    return []
+
+
+def main():
+    bad = 0
+    seen = set()
+    report = []
+    names = sorted(f[:-4] for f in os.listdir(CSRC) if f.endswith(".hip")
+                   and re.search(r"glds16|global_load_lds", open(os.path.join(CSRC, f)).read()))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        compiled = dict(zip(names, ex.map(compile_s, names)))
+    for fname in names:
+        funcs = functions(compiled[fname])
+        for name, ev in funcs.items():
+            if not any(k == "dma" for k, _ in ev):
+                continue
+            spec = next((s for f, rx, s in SPECS if f == fname and re.search(rx, name)), None)
+            short = re.sub(r"^_Z\d+", "", name)[:70]
+            if spec is None:
+                bad += 1
+                report.append(f"FAIL {fname}:{short}: LDS-DMA kernel without a protocol spec in tools/dma_isa_check.py")
+                continue
+            seen.add((fname, spec.get("kind")))
+            if spec["kind"] == "fifo":
+                pro, body = main_loop(ev)
+                if body is None:
+                    bad += 1; report.append(f"FAIL {fname}:{short}: no main loop with DMA + LDS reads found"); continue
+                sp = dict(spec)
+                if sp["need"] is None: sp["need"] = gemm256_need_factory()
+                errs, n = replay(pro, body, sp)
+                if errs:
+                    bad += 1
+                    report.append(f"FAIL {fname}:{short}: " + "; ".join(errs[:3]))
+                else:
+                    report.append(f"ok   {fname}:{short}: fifo protocol holds in the strict form over 6 replayed iterations ({n} DMA instructions)")
+            elif spec["kind"] == "sk4":
+                continue
+            elif spec["kind"] == "halo_stag":
+                # steady state of the tap loop (two K tiles per iteration): [16 fragment reads, stage W(t+2), vmcnt(2), barrier, MFMAs, barrier];
+                # replayed behind the protocol's own prologue (halo = tile 0 as one group, W(0), W(1), vmcnt(2), two barriers)
+                pro, body = main_loop(ev)
+                flat = [e for e in ev if e[0] in ("dma", "wait", "bar", "read")]
+                first_read = next(k for k, e in enumerate(flat) if e[0] == "read")
+                w2 = max(k for k, e in enumerate(flat[:first_read]) if e == ("wait", 2))
+                nbar = sum(1 for e in flat[w2:first_read] if e[0] == "bar")
+                nj = sum(1 for e in flat[:w2] if e[0] == "dma") - 4
+                state = {"n": 0}
+
+                def need(i, cls, state=state):
+                    t = state["n"] // 16; state["n"] += 1
+                    return 1 + t                                   # W(t) (the halo, tile 0, is older: FIFO)
+                synth = [("dma", None)] * 6 + [("wait", 2), ("bar", None), ("bar", None)]      # halo as one 2-instruction group + W0 + W1
+                errs, n = ([], 0) if body is None else replay(synth, body, dict(g=2, need=need, tile_cls=lambda n: 1 if n else 0,
+                                                                                 slot_reuse=lambda c: 4 if c else 10 ** 6, strict=True))
+                if body is None or errs or nbar < 2 or nj not in (4, 11):
+                    bad += 1
+                    report.append(f"FAIL {fname}:{short}: " + ("; ".join(errs[:3]) if errs else f"prologue: {nbar} barrier(s) between the retiring vmcnt(2) and the first read, {nj} halo DMAs"))
+                else:
+                    report.append(f"ok   {fname}:{short}: weight ring strict over 6 replayed iterations; halo ({nj} DMAs) + W(0) retired {nbar} barriers before the first read")
+            else:
+                report.append(f"note {fname}:{short}: {spec['kind']} -- {spec['why']}")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sk4_isa_check.py"), os.path.join(OUT, "gemm.s")], capture_output=True, text=True)
+    report.append("sk4: " + p.stdout.strip().splitlines()[-1])
+    if p.returncode != 0:
+        bad += 1
+        report += p.stdout.strip().splitlines()[:5]
+    print("\n".join(report))
+    print(f"{bad} failed")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
