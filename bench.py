@@ -197,7 +197,7 @@ def launch_check(args, world, rank):
     assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1"
     if world > 1:
         import datetime
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ.get("PG_DIST_TIMEOUT_S", "300"))))
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=float(os.environ.get("PG_DIST_TIMEOUT_S", "900"))))
     die = os.environ.get("PG_TEST_DIE_RANK")                # test hook: this rank exits before the first collective
     if die is not None and int(die) == rank:
         sys.stderr.write(f"bench.py: rank {rank} dying on request (PG_TEST_DIE_RANK)\n")
@@ -243,7 +243,7 @@ def run_rank(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PG_DIST_BACKEND", "nccl")    # "nccl" is RCCL on ROCm
         import datetime
-        tmo = datetime.timedelta(seconds=float(os.environ.get("PG_DIST_TIMEOUT_S", "300")))      # finite: a dead peer fails the collective
+        tmo = datetime.timedelta(seconds=float(os.environ.get("PG_DIST_TIMEOUT_S", "900")))      # finite: a dead peer fails the collective
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:

@@ -556,6 +556,10 @@ int pg_engine::create() {
     if (ng && ng[0] == '1') use_graph = false;
     const char* ug = getenv("PG_USE_GRAPH");
     if (ug && ug[0] == '1') use_graph = true;
+    // dalloc zero-fills every allocation with hipMemsetAsync on the NULL stream; the caller's streams may be non-blocking ones
+    // (PyTorch side streams do not order with the legacy default stream), so the fills must have landed before any of them runs
+    // (a still-queued memset could land on a workspace after the first op wrote it).
+    HIPCHK(hipStreamSynchronize(nullptr));
     return PG_OK;
 }
 

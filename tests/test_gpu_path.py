@@ -19,7 +19,7 @@ from oracle import ref_cpu as R
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL_F32 = 2e-3
-LOGIT_TOL_BF16 = 0.35          # CFG (w=5) amplifies bf16 rounding of O(1) logits by up to 11x
+LOGIT_TOL_BF16 = 0.02          # tiny config: measured max 0.0084 on MI355X (round 3; logits ~0.1 in magnitude at width 256); bound = 2.4x measured.  The full-width bounds live in test_gpu_fullwidth.py
 HIDDEN_TOL_BF16 = 0.08
 PIXEL_MSE = 1e-4
 
@@ -114,6 +114,7 @@ def test_decode_bf16_teacher_forced(tiny_cfg, tiny_weights):
     toks, logits = e.decode_image_tokens(cfg_weight=5.0, temperature=0.0, force_tokens=gold_tok, return_logits=True)
     ref = torch.from_numpy(g["logits"])                    # [T, B, V]
     err = (logits.cpu() - ref).abs().max().item()
+    print(f"tiny bf16 teacher-forced: max |logit err| {err:.4f} (bound {LOGIT_TOL_BF16})")
     assert err < LOGIT_TOL_BF16, err
     top2 = ref.topk(2, dim=-1).values
     decisive = (top2[..., 0] - top2[..., 1]) > 2 * LOGIT_TOL_BF16   # [T, B]
