@@ -205,3 +205,8 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
         }
     }
 }
+
+// rotate_half RoPE of one (x[j], x[j+64]) pair with EXPLICIT contraction, shared by rope_kv_kernel and the 256x256 GEMM's RoPE epilogue so
+// the fused and the unfused prefill write identical bits (left to the compiler, `a*c - b*s` may contract either product)
+__device__ __forceinline__ float rope_lo(float x0, float x1, float c, float s) { return __builtin_fmaf(x0, c, -(x1 * s)); }   // out[j]    = x0 cos - x1 sin
+__device__ __forceinline__ float rope_hi(float x0, float x1, float c, float s) { return __builtin_fmaf(x1, c, x0 * s); }      // out[j+64] = x1 cos + x0 sin

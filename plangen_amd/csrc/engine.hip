@@ -69,7 +69,8 @@ struct pg_engine {
     std::map<std::string, Slot> slots_map;
 
     // ---- weights
-    struct Layer { void *wqkv, *wo, *wgu, *wd, *ln1, *ln2; void *wqkv_t = nullptr, *wo_t = nullptr, *wgu_t = nullptr, *wd_t = nullptr; };
+    struct Layer { void *wqkv, *wo, *wgu, *wd, *ln1, *ln2; void *wqkv_t = nullptr, *wo_t = nullptr, *wgu_t = nullptr, *wd_t = nullptr;
+                   void* wqkv_p = nullptr; };      // wqkv_p: [8 | 8]-interleaved q / k rows for the prefill RoPE epilogue (bf16)
     void *gh_w1_t = nullptr, *gh_w2_t = nullptr, *lm_head_t = nullptr;
     int tile_one(hipStream_t s, const void* src, void** dst, int N, int K);
     std::vector<Layer> layers;
@@ -127,6 +128,8 @@ struct pg_engine {
     hipGraphExec_t gexec_txt = nullptr; std::vector<int64_t> gkey_txt;      // text-decode step (lm_head + argmax + stack)
     void drop_graphs() { if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; } if (gexec_txt) { (void)hipGraphExecDestroy(gexec_txt); gexec_txt = nullptr; } }
     bool use_graph = false;   // decode step replayed as a hipGraph; OFF by default: same-stream launches measure 1 % (bs=64) to 3.3 % (bs=8/16) faster than graph replay on ROCm 7.2 and the host loop keeps ahead at every batch size
+    bool prefill_rope_epi = true;     // prefill QKV: RoPE + KV write in the 256x256 GEMM's epilogue when the shape takes that kernel (0: GEMM -> fp32 q|k|v -> rope_kv_kernel)
+    bool prefill_res_epi = true;      // prefill o / down: residual add in the GEMM epilogue (0: slab + norm-kernel form, for A/B)
     bool time_attn = false; bool fuse_rope = true; bool force_swiglu = true; bool gn_fuse = true; bool mid_bf16 = true; int cu_split = 0;
     bool skip_attn = false;                                      // measurement only: the decode step WITHOUT its attention launches (bench.py's graph-replayed GEMM + norm phase time)
     // per-kernel-class HIP-event timing of the decode loop (eager instrumented pass, pg_set_option("time_attn", 1)):
@@ -189,6 +192,7 @@ struct pg_engine {
     int finalize(int* missing, hipStream_t s);
     int prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtype, const int32_t* pad_len, int R_, int L_,
                 int pmode, void* hidden_out, int hidden_dtype, hipStream_t s);
+    template <typename T> void gemm_residual(hipStream_t s, const T* a, const T* W, int M, int N, int K);
     template <typename T> void gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, int K, bool allow_skinny, const void* Wt = nullptr);
     template <typename T> void run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t* advance = nullptr);
     template <typename T> void head_logits(hipStream_t s, const T* in, int M);
@@ -679,6 +683,10 @@ int pg_engine::finalize(int* missing, hipStream_t s) {
         const int Hh2 = H(), I = cfg.inter, HDm = HD();
         for (Layer& ly : layers) {
             TRY(tile_one(s, ly.wqkv, &ly.wqkv_t, 3 * HDm, Hh2));
+            if ((Hh2 & 7) == 0) {      // prefill copy for the fused RoPE / KV-write epilogue (gemm256 act 3); 25 MB per layer at Janus-Pro-1B size
+                if (!ly.wqkv_p) TRY(dalloc(&ly.wqkv_p, (size_t)3 * HDm * Hh2 * 2));
+                launch_interleave_qk(s, (const bf16*)ly.wqkv, (bf16*)ly.wqkv_p, cfg.n_heads, Hh2);
+            }
             TRY(tile_one(s, ly.wo, &ly.wo_t, Hh2, HDm));
             TRY(tile_one(s, ly.wgu, &ly.wgu_t, 2 * I, Hh2));
             TRY(tile_one(s, ly.wd, &ly.wd_t, Hh2, I));
@@ -721,6 +729,17 @@ void pg_engine::gemm_llm(hipStream_t s, const T* a, const T* W, int M, int N, in
     S_last = 1;
 }
 
+// Prefill form of the two projections that end a residual branch: x[M,N] (fp32 residual stream) += a . W^T in the GEMM's own epilogue
+// (every element is read and written by the same lane), so the norm kernel that follows has no slab to fold in (S_last = 0): it reads x
+// and writes xn only -- 220 MB less traffic per norm at the bench's 13.4 k packed tokens.  Same fp32 sum as the slab form (x + acc), bit for bit.
+template <typename T>
+void pg_engine::gemm_residual(hipStream_t s, const T* a, const T* W, int M, int N, int K) {
+    GemmA ga; ga.ptr = a; ga.lda = K;
+    GemmEpi e; e.out = x; e.out_f32 = 1; e.ldc = N; e.residual = x; e.res_f32 = 1;
+    launch_gemm<T>(s, ga, W, K, 0, e, M, N, K, 1);
+    S_last = 0; slab_last = (long)M * N;
+}
+
 // The layer stack on M token rows.  mode 0: decode (row m = batch row, slot len+n_dec);
 // mode 1: prefill (packed prompt tokens).  Residual stream x fp32 [M,H]; ends with the final
 // RMSNorm written to final_out (T).  Every GEMM leaves fp32 split-K slabs in ``part``; the
@@ -741,7 +760,20 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);
         toc(s, TC_NORM, norm_bytes(S_pend));
         tic(s);
-        gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk, ly.wqkv_t);
+        bool qkv_fused = false;
+        if constexpr (std::is_same<T, bf16>::value) {
+            // prefill: RoPE(q), RoPE(k) and the KV-cache write in the QKV GEMM's own epilogue when the packed batch is big enough
+            // for the 256x256 kernel; smaller batches keep GEMM -> fp32 q|k|v -> rope_kv_kernel on the un-interleaved weights
+            if (mode == 1 && prefill_rope_epi && ly.wqkv_p) {
+                GemmA ga; ga.ptr = xn; ga.lda = Hh;
+                GemmEpi ge; ge.act = 3; ge.out = qbuf; ge.out_f32 = 0; ge.ldc = 3 * HDm;
+                ge.rope.qbuf = qbuf; ge.rope.kc = kc(li); ge.rope.vc = vc(li); ge.rope.cos_t = cos_t; ge.rope.sin_t = sin_t;
+                ge.rope.tok_row = d_tok_row; ge.rope.tok_j = d_tok_j; ge.rope.pos_off = d_pos_off;
+                ge.rope.nh = cfg.n_heads; ge.rope.slots = slots; ge.rope.max_pos = max_pos;
+                qkv_fused = gemm256_try(s, ga, (const bf16*)ly.wqkv_p, Hh, 0, ge, M, 3 * HDm, Hh, 1, 1, 0);
+            }
+        }
+        if (!qkv_fused) gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk, ly.wqkv_t);
         toc(s, TC_QKV, 3.0 * HDm * Hh * wb);
         if (mode == 0 && skip_attn) {
             // nothing: the GEMM + norm phase alone (outputs are garbage by construction)
@@ -750,8 +782,9 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
             launch_attn_decode_fused<T>(s, part, S_last, slab_last, (T*)obuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), M,
                                         cfg.n_heads, slots, max_pos, scale);
         } else {
-            launch_rope_kv<T>(s, part, S_last, slab_last, (T*)qbuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), mode, M,
-                              cfg.n_heads, slots, max_pos);
+            if (!qkv_fused)
+                launch_rope_kv<T>(s, part, S_last, slab_last, (T*)qbuf, (T*)kc(li), (T*)vc(li), cos_t, sin_t, seq(), mode, M,
+                                  cfg.n_heads, slots, max_pos);
             tic(s);
             bool done = false;
             if constexpr (std::is_same<T, bf16>::value) {
@@ -770,7 +803,8 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
             toc(s, TC_ATTN, keys * cfg.n_heads * 128 * 2 * (double)esz);
         }
         tic(s);
-        gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk, ly.wo_t);
+        if (!sk && prefill_res_epi) gemm_residual<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm);      // prefill: x += o . Wo^T in the GEMM's epilogue
+        else gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk, ly.wo_t);
         toc(s, TC_O, (double)Hh * HDm * wb);
         tic(s);
         launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);
@@ -796,7 +830,8 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         }
         toc(s, TC_GU, 2.0 * I * Hh * wb);
         tic(s);
-        gemm_llm<T>(s, (const T*)hbuf, (const T*)ly.wd, M, Hh, I, sk, ly.wd_t);
+        if (!sk && prefill_res_epi) gemm_residual<T>(s, (const T*)hbuf, (const T*)ly.wd, M, Hh, I);         // prefill: x += h . Wd^T
+        else gemm_llm<T>(s, (const T*)hbuf, (const T*)ly.wd, M, Hh, I, sk, ly.wd_t);
         toc(s, TC_DOWN, (double)Hh * I * wb);
         S_pend = S_last; slab_pend = slab_last;
     }
@@ -1547,6 +1582,8 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "attn_waves")) { h->tune.attn_waves = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->tune_epoch++; return PG_OK; }
+    if (!strcmp(key, "prefill_res_epi")) { h->prefill_res_epi = value != 0; return PG_OK; }
+    if (!strcmp(key, "prefill_rope_epi")) { h->prefill_rope_epi = value != 0; return PG_OK; }
     if (!strcmp(key, "attn_variant")) { h->tune.attn_variant = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "prefill_attn")) { h->tune.prefill_attn = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "ln_wave")) { h->tune.ln_wave = (int)value; return PG_OK; }

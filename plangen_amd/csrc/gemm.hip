@@ -561,6 +561,20 @@ void launch_tile_weights(hipStream_t s, const bf16* src, bf16* dst, int N, int K
     hipLaunchKernelGGL(tile_weights_kernel, dim3(blocks), dim3(256), 0, s, src, dst, N, K);
 }
 
+// Row re-ordering of Wqkv for the prefill RoPE epilogue (RopeEpi): new row 16t + p of a q / k head = old row 8t + p (p < 8) or 64 + 8t + p - 8.
+__global__ void interleave_qk_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int nh, int K) {
+    const int n = blockIdx.x, HD = nh * 128;
+    const int sec = n / HD, hc = n - sec * HD, head = hc >> 7, c = hc & 127;
+    int so = c;
+    if (sec < 2) { const int t = c >> 4, p = c & 15; so = p < 8 ? 8 * t + p : 64 + 8 * t + p - 8; }
+    const u32x4* sp = (const u32x4*)(src + ((long)sec * HD + head * 128 + so) * K);
+    u32x4* dp = (u32x4*)(dst + (long)n * K);
+    for (int i = threadIdx.x; i < K / 8; i += blockDim.x) dp[i] = sp[i];
+}
+void launch_interleave_qk(hipStream_t s, const bf16* src, bf16* dst, int nh, int K) {
+    hipLaunchKernelGGL(interleave_qk_kernel, dim3(3 * nh * 128), dim3(256), 0, s, src, dst, nh, K);
+}
+
 template <int EPI, bool TILED>
 static bool sk3_prod_tiled(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
     const int nck = K / SK_BK / S;

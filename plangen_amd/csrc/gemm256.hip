@@ -42,8 +42,9 @@
 
 __device__ __forceinline__ void g2_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <class AL, class EP, int WM, int WN>
-__global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
+template <class AL, class EP, int WM, int WN, bool ROPE = false>      // ROPE: the prefill QKV instantiation (RoPE + KV-write epilogue, act 3) -- its own kernel so its
+__global__ __launch_bounds__(512) void gemm256_kernel(                 // register needs do not reach the other users of this template
+AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                                                      long strideA2, long strideB2, EP ep, int M, int N, int K, int ntm, int ntn) {
     static_assert(WM * WN == 8 && (WN == 2 || WN == 4), "eight waves, 128x64 of C each");
     constexpr int BM = WM * 128, BN = WN * 64;
@@ -205,7 +206,76 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
         base += G;
         have = base < NT && setup(base);
         if (have) prologue();
-        if (ep.e.act == 2) {
+        if constexpr (ROPE) {
+            // Prefill QKV projection: RoPE(q), RoPE(k) and the KV-cache write from the accumulators.  W rows of the q / k heads
+            // are interleaved [8 | 8] per n-tile (launch_interleave_qk): lanes g = 0,1 hold rotary columns j = 8t + 4g .. +3, lanes g = 2,3
+            // (lane ^ 32) the partners j + 64 of the same token -- one cross-half exchange, then out[j] = x[j] cos - x[j+64] sin,
+            // out[j+64] = x[j+64] cos + x[j] sin (rotate_half form, the arithmetic of rope_kv_kernel), 4 bf16 = 8 bytes per store.
+            // The fp32 q|k|v tensor and the separate RoPE / KV-fill pass disappear.
+            const RopeEpi& R = ep.e.rope;
+            const int HDm = R.nh * 128;
+            // per-row metadata of the lane's 8 rows first (two dependent round trips for all of them); the cos / sin rows of m-tile mt+1 are
+            // requested under the stores of m-tile mt (single-buffered: the accumulators leave ~60 VGPRs, a double buffer spilled)
+            int rowv[8], slotv[8], posv[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int m = em0 + mt * 16, mc = m < M ? m : M - 1;
+                rowv[mt] = R.tok_row[mc]; slotv[mt] = R.tok_j[mc];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int pos = R.pos_off[rowv[mt]] + slotv[mt];
+                posv[mt] = pos < R.max_pos ? pos : R.max_pos - 1;
+            }
+            int secv[4], headv[4], tv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                int c0 = ecol0 + nt * 16;                                       // wave-uniform: the n-tile's first column
+                secv[nt] = c0 < N ? c0 / HDm : 3;                               // 3: past the matrix (nothing stored)
+                c0 = c0 < N ? c0 : 0;
+                const int hc = c0 - (c0 / HDm) * HDm;
+                headv[nt] = hc >> 7; tv[nt] = (hc & 127) >> 4;
+            }
+            f32x4 cs[4], sn[4];
+            auto fetch = [&](int mt) __attribute__((always_inline)) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const long o = (long)posv[mt] * 64 + 8 * tv[nt] + 4 * (g & 1);
+                    cs[nt] = *(const f32x4*)(R.cos_t + o); sn[nt] = *(const f32x4*)(R.sin_t + o);
+                }
+            };
+            fetch(0);
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int m = em0 + mt * 16, row = rowv[mt], slot = slotv[mt];
+                const bool ok = m < M && slot < R.slots;
+                uint2 q[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const f32x4 v = acc[mt][nt];
+                    float o[4] = {v[0], v[1], v[2], v[3]};
+                    if (secv[nt] < 2) {
+                        f32x4 u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) u[j] = __shfl_xor(v[j], 32, 64);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = g < 2 ? rope_lo(v[j], u[j], cs[nt][j], sn[nt][j]) : rope_hi(u[j], v[j], cs[nt][j], sn[nt][j]);   // lanes g >= 2 hold x[j+64] (v), receive x[j] (u)
+                    }
+                    q[nt].x = pack_bf16x2(o[0], o[1]); q[nt].y = pack_bf16x2(o[2], o[3]);
+                }
+                if (mt + 1 < 8) fetch(mt + 1);                                  // in flight under this m-tile's stores
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int sec = secv[nt], head = headv[nt], t = tv[nt];
+                    if (sec > 2 || !ok) continue;
+                    bf16* dst;
+                    if (sec == 0) dst = (bf16*)R.qbuf + (long)m * HDm + head * 128 + (g < 2 ? 0 : 64) + 8 * t + 4 * (g & 1);
+                    else if (sec == 1) dst = (bf16*)R.kc + (((long)row * R.nh + head) * R.slots + slot) * 128 + (g < 2 ? 0 : 64) + 8 * t + 4 * (g & 1);
+                    else dst = (bf16*)R.vc + (((long)row * R.nh + head) * R.slots + slot) * 128 + 16 * t + 4 * g;
+                    *(uint2*)dst = q[nt];
+                }
+            }
+        } else if (ep.e.act == 2) {
             // SwiGLU epilogue: W rows are interleaved [8 gate | 8 up] per 16-column n-tile (the engine's gate|up
             // layout), so lanes g = 0,1 hold 4 gate columns and lanes g = 2,3 (lane ^ 32) the matching 4 up columns
             // of the same row: one cross-half exchange, then h = silu(gate) * up goes out as 4 bf16 (8 bytes)
@@ -245,14 +315,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(AL al, const bf16* __restr
 }
 
 
-template <class AL, int WM, int WN>
+template <class AL, int WM, int WN, bool ROPE = false>
 static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long strideA, long strideB, long strideA2, long strideB2,
                       const Epi<bf16>& ep, int M, int N, int K, int batch, int batch2) {
     constexpr int BM = WM * 128, BN = WN * 64, LDS = 2 * (2 * WM * 64 * 128 + 2 * WN * 32 * 128);
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int per_batch = 256 / (batch * batch2) > 8 ? 256 / (batch * batch2) : 8;   // blocks per (batch) slice: one per CU overall
     dim3 grid(ntm * ntn < per_batch ? ntm * ntn : per_batch, batch, batch2), block(512);
-    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN>;
+    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN, ROPE>;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
@@ -273,9 +343,11 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
     Epi<bf16> ep{e, M, N};
     if (a.kind == 0) {
         PlainLoaderB<bf16> al; al.A = (const bf16*)a.ptr; al.lda = a.lda; al.M = M;
-        launch256<PlainLoaderB<bf16>, 2, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+        if (e.act == 3) launch256<PlainLoaderB<bf16>, 2, 4, true>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+        else launch256<PlainLoaderB<bf16>, 2, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
         return true;
     }
+    if (e.act == 3) return false;
     const int Ho = a.kind == 2 ? a.Hi / 2 : (a.Hi << a.up), Wo = a.kind == 2 ? a.Wi / 2 : (a.Wi << a.up);
     const long in_elems = ((long)M / ((long)Ho * Wo)) * a.Hi * a.Wi * a.Cin;
     if (in_elems >= (1L << 31)) return false;             // the slim loader keeps 32-bit element offsets

@@ -36,6 +36,16 @@ struct GemmA {
     void* gn_part = nullptr;            // optional: GroupNorm partials of the OUTPUT (kernels that support it set *gn_nsplit > 0)
     int* gn_nsplit = nullptr;
 };
+// act == 3 (256x256 kernel, prefill QKV projection): RoPE(q), RoPE(k) and the KV-cache write straight from the accumulators.
+// W must be the [8 | 8]-interleaved copy of Wqkv (launch_interleave_qk): n-tile t of a q / k head holds rotary columns 8t..8t+7 and
+// 64+8t..64+8t+7, so lanes l and l ^ 32 hold x[j] and x[j+64] of the same token; v heads keep their column order.
+struct RopeEpi {
+    void* qbuf = nullptr; void* kc = nullptr; void* vc = nullptr;      // bf16: q [M][nh*128]; caches [R][nh][slots][128]
+    const float* cos_t = nullptr; const float* sin_t = nullptr;        // [max_pos][64]
+    const int32_t* tok_row = nullptr; const int32_t* tok_j = nullptr;  // packed token m -> (row, slot)
+    const int32_t* pos_off = nullptr;                                  // [R] RoPE position of slot 0
+    int nh = 0, slots = 0, max_pos = 0;
+};
 // Epilogue: v = acc*scale + bias_n[col] + bias_m[row] + residual[row,col]; act; store.
 struct GemmEpi {
     void* out = nullptr;
@@ -47,7 +57,8 @@ struct GemmEpi {
     int res_f32 = 0;
     long ldr = 0, strideR = 0;
     float scale = 1.f;
-    int act = 0;                        // 0 none, 1 gelu(erf); 2 (256x256 kernel only) SwiGLU over [8 gate | 8 up] column blocks -> bf16 [M, N/2]
+    int act = 0;                        // 0 none, 1 gelu(erf); 2 (256x256 kernel only) SwiGLU over [8 gate | 8 up] column blocks -> bf16 [M, N/2]; 3 (256x256 only) RoPE + KV write (rope)
+    RopeEpi rope;
 };
 template <typename T>
 void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strideB,
@@ -76,6 +87,8 @@ bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16
 // Wt: optional tiled decode copy of W (launch_tile_weights); preferred when present
 void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, const bf16* Wt = nullptr);
 void launch_tile_weights(hipStream_t s, const bf16* src, bf16* dst, int N, int K);
+// dst = Wqkv [3*nh*128, K] with the rows of every q / k head re-ordered [8 | 8] per 16-row tile (RopeEpi); v rows copied
+void launch_interleave_qk(hipStream_t s, const bf16* src, bf16* dst, int nh, int K);
 int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
 
 // ---------------------------------------------------------------- LLM elementwise / attention

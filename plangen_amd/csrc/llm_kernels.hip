@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(const float* __restrict__ 
     const float q0 = a6[0], q1 = a6[1], k0 = a6[2], k1 = a6[3], v0 = a6[4], v1 = a6[5];
     const float c = cos_t[(long)pos * 64 + j], sn = sin_t[(long)pos * 64 + j];
     T* qo = qbuf + (long)m * HD + head * 128 + j;
-    ET<T>::st(qo, q0 * c - q1 * sn);
-    ET<T>::st(qo + 64, q1 * c + q0 * sn);
+    ET<T>::st(qo, rope_lo(q0, q1, c, sn));
+    ET<T>::st(qo + 64, rope_hi(q0, q1, c, sn));
     const long co = (((long)row * nh + head) * slots + slot) * 128 + j;
-    ET<T>::st(kc + co, k0 * c - k1 * sn);
-    ET<T>::st(kc + co + 64, k1 * c + k0 * sn);
+    ET<T>::st(kc + co, rope_lo(k0, k1, c, sn));
+    ET<T>::st(kc + co + 64, rope_hi(k0, k1, c, sn));
     ET<T>::st(vc + co, v0);
     ET<T>::st(vc + co + 64, v1);
 }

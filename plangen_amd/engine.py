@@ -410,7 +410,7 @@ class Engine:
 
     # ------------------------------------------------------------------ test taps
     def debug_read(self, name: str, index: int, numel: int, dtype) -> torch.Tensor:
-        out = torch.empty((numel,), dtype=dtype, device=self.device)
+        out = torch.zeros((numel,), dtype=dtype, device=self.device)       # the library copies min(numel, buffer size): the rest stays zero
         self._check(self.lib.pg_debug_read(self.h, name.encode(), index, self._p(out), out.numel() * out.element_size(),
                                            self.stream), "pg_debug_read")
         return out
