@@ -203,6 +203,9 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *   lpt_order (1)       longest rows first in the decode-attention launch
  *   attn_variant, attn_waves (0; 4 pins 4-wave blocks)   decode-attention kernel variants
  *   prefill_attn (2)    MFMA prefill attention: 2 = 128 queries per block, K/V by LDS-DMA, V through the LDS transpose read; 1 = 64-query kernel
+ *   prefill_rope_epi (1) prefill QKV projection: RoPE + KV-cache write in the 256x256 GEMM's epilogue when the packed batch takes that kernel
+ *                       (plangen_base.py:571 -> LlamaAttention.forward); 0 = GEMM -> fp32 q|k|v -> RoPE / KV-fill kernel.  Same bits either way.
+ *   prefill_res_epi (1) prefill o_proj / down_proj: residual add in the GEMM epilogue; 0 = fp32 slab folded in by the norm kernel.  Same bits.
  *   ln_wave (1)         SigLIP LayerNorm (width 1024): wave-per-row register kernel; 0 = block-per-row kernel
  *   gemm256 (1)         256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)
  *   conv_halo (1)       direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: off)
