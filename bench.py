@@ -150,18 +150,23 @@ def spawn_ranks(n, argv, poll_s=0.2, grace_s=5.0):
                                       stdout=out0 if r == 0 else None, start_new_session=True))
     rcs = [None] * n
     failed = None
-    while any(rc is None for rc in rcs):
-        for r, p in enumerate(procs):
-            if rcs[r] is None:
-                rcs[r] = p.poll()
-                if rcs[r] not in (None, 0) and failed is None:
-                    failed = r
-        if failed is not None:
-            break
-        time.sleep(poll_s)
+    interrupted = False
+    try:
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p.poll()
+                    if rcs[r] not in (None, 0) and failed is None:
+                        failed = r
+            if failed is not None:
+                break
+            time.sleep(poll_s)
+    except BaseException:                                      # Ctrl-C / SIGTERM of the launcher: the ranks live in their own sessions and would survive it
+        interrupted = True
+        failed = next((r for r in range(n) if rcs[r] is None), 0)
     if failed is not None:
-        sys.stderr.write(f"bench.py: rank {failed} exited with rc {rcs[failed]}; terminating the other ranks\n")
-        live = [p for r, p in enumerate(procs) if rcs[r] is None]
+        sys.stderr.write(("bench.py: launcher interrupted" if interrupted else f"bench.py: rank {failed} exited with rc {rcs[failed]}") + "; terminating the other ranks\n")
+        live = [p for r, p in enumerate(procs) if p.poll() is None]
         for p in live:
             try:
                 os.killpg(p.pid, signal.SIGTERM)          # the rank's own process group (start_new_session): exact PIDs, no pattern
@@ -178,6 +183,8 @@ def spawn_ranks(n, argv, poll_s=0.2, grace_s=5.0):
                     pass
                 p.wait()
         rcs = [p.returncode for p in procs]
+        if interrupted:
+            return 130
     out0.seek(0)
     sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
@@ -273,9 +280,13 @@ def run_rank(args):
     ids, mask, lo, hi, nB = broadcast_prompts(g_ids, g_mask, dev)
     pad = Engine.pad_len_from_mask(mask, L)
     eng.set_option("rng_image_offset", lo)       # sampling noise keyed on the GLOBAL image index: sharding does not change tokens
+    # The collate builds the uncond rows on the HOST by replicating one negative prompt (plangen_base.py:672-686), so "do all uncond rows
+    # share their ids" is host knowledge: compared once here on the host copy and handed to every pg_prefill as a hint -- the library then
+    # skips its device probe (a 4-byte read + stream sync per batch).
+    uncond_shared = Engine.uncond_rows_shared(ids.cpu(), pad)
 
     def step(seed, n_tok=T, decode_pixels=True):
-        eng.prefill(ids, pad, position_mode=0)
+        eng.prefill(ids, pad, position_mode=0, uncond_shared=uncond_shared)
         toks = eng.decode_image_tokens(T=n_tok, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=seed)
         img = eng.vq_decode(toks) if (decode_pixels and n_tok == cfg.img_tokens) else None
         all_toks = gather_rows(toks, nB)          # rank 0: [G, T]; others: None

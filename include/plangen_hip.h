@@ -202,6 +202,9 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *   cu_split (0)        with lanes=2: complementary CU masks on the lane streams (1-4: mask patterns)
  *   lpt_order (1)       longest rows first in the decode-attention launch
  *   attn_variant, attn_waves (0; 4 pins 4-wave blocks)   decode-attention kernel variants
+ *   uncond_shared_hint  ONE-SHOT, consumed by the next pg_prefill: 1 = the caller has compared the ids on the host (its collate built them,
+ *                       plangen_base.py:672-686 replicates one negative prompt) and every odd row equals row 1 -> no device probe, pg_prefill does
+ *                       not synchronise; 0 = they differ; -1 (default) = probe on the device (one 4-byte read + stream sync)
  *   prefill_attn (2)    MFMA prefill attention: 2 = 128 queries per block, K/V by LDS-DMA, V through the LDS transpose read; 1 = 64-query kernel
  *   prefill_rope_epi (1) prefill QKV projection: RoPE + KV-cache write in the 256x256 GEMM's epilogue when the packed batch takes that kernel
  *                       (plangen_base.py:571 -> LlamaAttention.forward); 0 = GEMM -> fp32 q|k|v -> RoPE / KV-fill kernel.  Same bits either way.

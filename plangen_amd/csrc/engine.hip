@@ -168,6 +168,7 @@ struct pg_engine {
     void* kc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 0) * kv_layer_elems() * esz + kv_row_off; }
     void* vc(int layer) const { return (char*)kv + ((size_t)layer * 2 + 1) * kv_layer_elems() * esz + kv_row_off; }
     int shared_len = 0, shared_row = 1; bool share_uncond = true;
+    int uncond_hint = -1;             // next pg_prefill only: 1 = caller guarantees every odd row carries row 1's ids, 0 = it does not, -1 = probe on the device (one 4-byte read + stream sync)
     // decode lanes: the batch's rows split into independent chains on separate streams
     size_t kv_row_off = 0;            // byte offset of the current lane's first row inside a K or V layer block
     int h_len_off = 0; int lanes_opt = -1;   // -1 auto, 1, 2
@@ -863,7 +864,8 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     if (share_uncond && fuse_rope && ids_dev && !hidden_out && pmode == 0 && R_ >= 4 && (R_ % 2) == 0) {
         bool same = true;
         for (int r = 3; r < R_ && same; r += 2) same = pad_len[r] == pad_len[1];
-        if (same) {
+        if (same && uncond_hint == 1) shared_len = L_ - pad_len[1];      // the caller compared the ids on the host (its collate built them): no probe, no sync
+        else if (same && uncond_hint != 0) {
             HIPCHK(hipMemsetAsync(d_flag, 0, 4, s));
             launch_rows_differ(s, ids_dev, L_, /*first*/ 3, /*stride*/ 2, /*ref row*/ 1, (R_ - 2) / 2, pad_len[1], d_flag);
             HIPCHK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, s));
@@ -871,6 +873,7 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
             if (*h_flag == 0) shared_len = L_ - pad_len[1];
         }
     }
+    uncond_hint = -1;                                                       // one-shot: the hint describes the ids of THIS call only
     // pinned staging is double-buffered: the copies of call n are still in flight while call n+1 fills
     // the other buffer; a buffer is reused only after the event recorded behind its copies has fired
     // (two calls back: in practice never waits), so pg_prefill itself does not synchronise the stream.
@@ -1545,6 +1548,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "force_swiglu")) { h->force_swiglu = value != 0; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "use_graph")) { h->use_graph = value != 0; return PG_OK; }
     if (!strcmp(key, "share_uncond")) { h->share_uncond = value != 0; return PG_OK; }
+    if (!strcmp(key, "uncond_shared_hint")) { h->uncond_hint = value < 0 ? -1 : (value != 0); return PG_OK; }
     if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
     if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
     if (!strcmp(key, "gemm256")) { h->tune.gemm256 = (int)value; return PG_OK; }

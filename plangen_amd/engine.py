@@ -303,8 +303,25 @@ class Engine:
             raise PlanGenError("attention_mask is not left-padded (0...01...1)")
         return (L - m.sum(-1)).tolist()
 
+    @staticmethod
+    def uncond_rows_shared(ids: torch.Tensor, pad_len: Sequence[int]) -> bool:
+        """Host-side form of the library's probe: every odd (uncond CFG) row carries row 1's padding and ids."""
+        R = ids.shape[0]
+        if R < 4 or R % 2:
+            return False
+        if any(int(pad_len[r]) != int(pad_len[1]) for r in range(3, R, 2)):
+            return False
+        return bool((ids[3::2, int(pad_len[1]):] == ids[1, int(pad_len[1]):]).all())
+
     def prefill(self, ids: torch.Tensor, pad_len: Sequence[int], position_mode: int = 0,
-                return_hidden: bool = False, hidden_dtype=torch.float32) -> Optional[torch.Tensor]:
+                return_hidden: bool = False, hidden_dtype=torch.float32, uncond_shared: Optional[bool] = None) -> Optional[torch.Tensor]:
+        """uncond_shared: None -> decided here when ``ids`` is still a HOST tensor (the collate's output; exact comparison, no device
+        sync inside pg_prefill), probed on the device otherwise; True / False -> the caller's own host-side answer (bench.py:
+        rank 0 compares the collated ids once and broadcasts the flag with them)."""
+        if uncond_shared is None and not ids.is_cuda and position_mode == 0 and not return_hidden:
+            uncond_shared = self.uncond_rows_shared(ids, pad_len)
+        if uncond_shared is not None:
+            self.set_option("uncond_shared_hint", int(bool(uncond_shared)))
         ids = self._dev(ids, torch.int32)
         R, L = ids.shape
         pl = (C.c_int32 * R)(*[int(v) for v in pad_len])

@@ -138,3 +138,17 @@ def test_package_pins_device_kernargs_for_the_stream_launched_loop():
     assert subprocess.check_output([sys.executable, "-c", code], env=env, cwd=root).decode().strip() == "1"
     env["HIP_FORCE_DEV_KERNARG"] = "0"
     assert subprocess.check_output([sys.executable, "-c", code], env=env, cwd=root).decode().strip() == "0"
+
+
+def test_uncond_rows_shared_host_check():
+    """Engine.uncond_rows_shared: the host-side form of pg_prefill's device probe (every odd row carries row 1's padding and ids)."""
+    from plangen_amd.engine import Engine
+    cond = [[5, 6, 7, 8], [9, 10], [4, 4, 4]]
+    ids, mask = t2i_infer_collate_batch(cond, [1, 2, 3], 0, 4)
+    pad = Engine.pad_len_from_mask(mask, ids.shape[1])
+    assert Engine.uncond_rows_shared(ids, pad)
+    ids2 = ids.clone(); ids2[5, -1] = 99
+    assert not Engine.uncond_rows_shared(ids2, pad)
+    ids3, mask3 = t2i_infer_collate_batch(cond, [[1, 2], [1, 2, 3], [1, 2]], 0, 4)           # per-sample negatives of different lengths
+    assert not Engine.uncond_rows_shared(ids3, Engine.pad_len_from_mask(mask3, ids3.shape[1]))
+    assert not Engine.uncond_rows_shared(ids[:2], pad[:2])                                    # a single pair: nothing to share
