@@ -236,3 +236,40 @@ def test_mmu_prompt_rows_use_the_chat_template(tmp_path):
     r = m.validation(0)
     assert r["batches"] == 2
     m.engine.close()
+
+
+def test_cli_end_to_end_on_real_format_files(tmp_path, tiny_cfg, tiny_weights):
+    """The command line a PlanGen user runs, on files in the reference's formats: `janus_path` holding HF safetensors weights AND
+    HF tokenizer files (HFCodec), `resume=<int>` -> `out_path/checkpoint-<int>/trainable_model_parameters.pth` overlay
+    (base_system.py:132-134, :153-155), JSONL TEXT rows (base_caption / gt_grounding / image_id), task uni_2stage: stage-1 layout
+    decode -> decode_plan_text_batch -> wrap_uni_prompt through the tokenizer -> CFG image decode -> PNG tree + layout JSON."""
+    from safetensors.torch import save_file
+    from test_text_cpu import _tiny_hf_tokenizer_dir
+    from project.plangen.plangen_base import System as CliSystem
+    jp = _tiny_hf_tokenizer_dir(tmp_path)                                        # tokenizer.json etc. (vocabulary < tiny_cfg.vocab)
+    keep = {k: v.contiguous() for k, v in tiny_weights.items()
+            if not k.startswith(("vision_model.", "aligner.", "gen_vision_model.encoder", "gen_vision_model.quant_conv"))}
+    save_file(keep, os.path.join(jp, "model.safetensors"))
+    out = tmp_path / "out"
+    ck = out / "checkpoint-3"
+    ck.mkdir(parents=True)
+    torch.save({"vl_gpt.gen_head.vision_head.bias": tiny_weights["gen_head.vision_head.bias"] + 0.25}, str(ck / "trainable_model_parameters.pth"))
+    rows = [{"base_caption": c, "gt_grounding": "<grounding><ref>a cat</ref><box>[1,2,300,400]</box></grounding>", "image_id": f"im{i}"}
+            for i, c in enumerate(["a red cat on the table", "two dogs playing in a field", "a cat", "the table"])]
+    f = tmp_path / "rows.jsonl"
+    f.write_text("\n".join(json.dumps(r) for r in rows))
+    a = _args(out, "uni_2stage", janus_path=jp, resume=3)
+    a.test_data = dict(a.test_data, data_file=str(f), data_name="creati")
+    m = CliSystem(a, None)
+    assert type(m.codec).__name__ == "HFCodec" and m.cfg.eos_id == m.codec.eos_token_id and m.cfg.pad_id == m.codec.pad_id
+    m.setup_data(None)
+    assert m.resume(None) == 0
+    r = m.validation(0)
+    base = os.path.join(str(out), "test", "creati_uni_2stage_2", "0")
+    assert r["out_dir"] == base and r["images"] == 4
+    assert sorted(os.listdir(os.path.join(base, "pr_image"))) == ["0.png", "1.png", "2.png", "3.png"]
+    assert sorted(os.listdir(os.path.join(base, "image_ids"))) == [f"im{i}.jpg" for i in range(4)]
+    lay = json.load(open(os.path.join(str(out), "test", "creati_uni_2stage_2", "0_batch", "0_layout.json")))
+    assert lay["base_caption"] == [rows[0]["base_caption"], rows[1]["base_caption"]]
+    assert all(t.startswith("<grounding>") and t.endswith("</grounding>") for t in lay["pr_grounding"])
+    m.engine.close()

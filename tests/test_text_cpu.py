@@ -147,3 +147,50 @@ def test_cli_integer_resume_maps_to_checkpoint_dir(tmp_path):
     os.makedirs(tmp_path / "checkpoint-7")
     with pytest.raises(FileNotFoundError, match="janus_path"):          # the overlay resolves; the base weights are what is missing now
         s.resume()
+
+
+def _tiny_hf_tokenizer_dir(tmp_path):
+    """A small byte-level BPE tokenizer saved in the HF layout (tokenizer.json + tokenizer_config.json + special_tokens_map.json) with the
+    Janus special tokens -- what VLChatProcessor.from_pretrained(janus_path).tokenizer loads, minus the real vocabulary (no network here)."""
+    from tokenizers import AddedToken, Tokenizer, decoders, models, pre_tokenizers, processors, trainers
+    from transformers import PreTrainedTokenizerFast
+    tok = Tokenizer(models.BPE())
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    specials = ["<｜begin▁of▁sentence｜>", T.SEP2, T.PAD_TAG, T.IMAGE_TAG, T.IMAGE_START_TAG, T.IMAGE_END_TAG, "<|User|>", "<|Assistant|>",
+                "<grounding>", "</grounding>", "<ref>", "</ref>", "<box>", "</box>"]
+    corpus = ["a red cat on the table", "two dogs playing in a field", "what is on the table?", "0 1 2 3 4 5 6 7 8 9 , [ ] : \n\n",
+              T.MMU_SYSTEM_PROMPT, "Describe the layout of the image."]
+    tok.train_from_iterator(corpus * 4, trainers.BpeTrainer(vocab_size=400, special_tokens=specials, initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    bos = tok.token_to_id(specials[0])
+    tok.post_processor = processors.TemplateProcessing(single=f"{specials[0]} $A", special_tokens=[(specials[0], bos)])
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, bos_token=specials[0], eos_token=T.SEP2, pad_token=T.PAD_TAG,
+                                   additional_special_tokens=[AddedToken(s, special=True) for s in specials[3:]])
+    d = tmp_path / "janus_tok"
+    fast.save_pretrained(str(d))
+    return str(d)
+
+
+def test_hf_codec_on_tokenizer_files(tmp_path):
+    """HFCodec (the path real Janus-Pro tokenizer files take): BOS prepended like tokenizer.encode, special tags are single ids,
+    pad / eos ids come from the files, decode keeps specials (plangen_base.py:294), and the mmu prompt expands its placeholder."""
+    d = _tiny_hf_tokenizer_dir(tmp_path)
+    assert os.path.exists(os.path.join(d, "tokenizer.json"))
+    c = T.HFCodec(d)
+    assert c.eos_token_id == c.token_id(T.SEP2) and c.pad_id == c.token_id(T.PAD_TAG)
+    prompt, ids = T.wrap_uni_prompt_ids(c, "a red cat on the table", "<grounding><ref>a cat</ref><box>[1,2,300,400]</box></grounding>")
+    assert ids[0] == c.bos_token_id and ids[-1] == c.token_id(T.IMAGE_START_TAG)
+    assert ids.count(c.token_id("<ref>")) == 1 and ids.count(c.token_id("<|User|>")) == 1 and ids.count(c.eos_token_id) == 1
+    assert c.decode(ids[1:]) == prompt
+    p1, ids1 = T.wrap_uni_prompt_ids(c, "two dogs", "<grounding>", in_stage1=True)
+    assert p1.endswith("<grounding>" + T.SEP2) and ids1[-1] == c.token_id("<grounding>")            # trailing EOS-tag token dropped (:259-260)
+    _, mids, slots = T.wrap_mmu_prompt_ids(c, "what is on the table?", 5)
+    k = mids.index(c.token_id(T.IMAGE_START_TAG))
+    assert mids[k + 1:k + 6] == [c.token_id(T.IMAGE_TAG)] * 5 and mids[k + 6] == c.token_id(T.IMAGE_END_TAG) and sum(slots) == 5
+    assert c.decode(mids[1:k]).startswith(T.MMU_SYSTEM_PROMPT) and c.decode(mids[k + 7:]).endswith("<|Assistant|>:")
+    with pytest.raises(KeyError):
+        c.token_id("<no_such_tag>")
+    # answers cut at the first EOS and parsed (decode_mmu_text_batch / trans_gr_to_creati on real tokenizer output)
+    ans = c.encode("<ref>a cat</ref><box>[12,40,500,620]</box>")[1:] + [c.eos_token_id] + c.encode("junk")[1:]
+    text = c.decode(T.cut_at_eos(ans, c.eos_token_id))
+    assert T.trans_gr_to_creati(text) == ([[0.012, 0.04, 0.5, 0.62]], ["a cat"])
