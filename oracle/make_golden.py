@@ -406,6 +406,48 @@ def golden_small_batch(T=288, B=8, NEG=200):
 
 
 @torch.no_grad()
+def golden_text_full_width(B=32, L=128, N=40):
+    """Greedy TEXT decode at Janus-Pro-1B width (the stage-1 layout decode of uni_2stage / the mmu answer, plangen_base.py:513-523):
+    32 left-padded prompts of 40..128 tokens, ``LlamaForCausalLM.generate`` of the installed transformers, greedy, 40 new tokens,
+    an EOS id chosen from a probe run so that several rows stop early.  Same seeded full-width weights as golden_full_width
+    (lm_head 2048 -> 4096).  The oracle restatement must reproduce ids and, teacher-forced, logits."""
+    torch.set_num_threads(8)
+    cfg = R.OracleCfg(**FULLW)
+    W = R.make_weights(cfg, seed=3)
+    lm = hf_llama(cfg, W, causal_lm=True)
+    g = torch.Generator().manual_seed(41)
+    prm = []
+    for b in range(B):
+        n = L if b == 0 else int(torch.randint(40, L + 1, (1,), generator=g))
+        row = torch.randint(8, cfg.vocab, (n,), generator=g).tolist()
+        row[0] = 1
+        prm.append(row)
+    ids, mask = R.pad_input_ids(prm, cfg.pad_id)
+    emb = lm.get_input_embeddings()(ids.long())
+    probe = lm.generate(inputs_embeds=emb, attention_mask=mask, pad_token_id=cfg.eos_id, bos_token_id=1, eos_token_id=cfg.eos_id,
+                        max_new_tokens=N, do_sample=False, use_cache=True)
+    # an id that ~a quarter of the rows emit somewhere in steps 5..30: those rows stop early, the rest run to the end
+    cand = torch.bincount(probe[:, 5:30].reshape(-1), minlength=cfg.vocab)
+    rows_with = torch.stack([(probe[:, 5:30] == t).any(1).sum() for t in cand.topk(64).indices])
+    eos = int(cand.topk(64).indices[(rows_with - B // 4).abs().argmin()])
+    out = lm.generate(inputs_embeds=emb, attention_mask=mask, pad_token_id=eos, bos_token_id=1, eos_token_id=eos,
+                      max_new_tokens=N, do_sample=False, use_cache=True)
+    mine = R.generate_text_greedy(W, cfg, R.embed_tokens(W, ids), mask, N, eos)
+    assert torch.equal(out, mine), (out.shape, mine.shape)
+    stopped = int(((out == eos).any(1)).sum())
+    assert 2 <= stopped < B, stopped
+    # teacher-forced logits of the un-stopped run (probe ids, EOS = the model's own so nothing is suppressed): [N, B, V] -> top-2 + 64 fixed columns
+    _, logits = R.generate_text_greedy(W, cfg, R.embed_tokens(W, ids), mask, N, cfg.eos_id, min_new_tokens=N, force_tokens=probe, return_logits=True)
+    gv = torch.Generator().manual_seed(43)
+    vsel = torch.randperm(cfg.vocab, generator=gv)[:64].sort().values
+    tv, ti = logits.topk(2, dim=-1)
+    np.savez_compressed(os.path.join(OUT, "generate_fullwidth.npz"), ids=ids.numpy().astype(np.int16), mask=mask.numpy().astype(np.int8),
+                        eos=eos, out=out.numpy().astype(np.int16), probe=probe.numpy().astype(np.int16), top_v=tv.numpy(), top_i=ti.numpy().astype(np.int16),
+                        vsel=vsel.numpy().astype(np.int16), sel_logits=logits[:, :, vsel].numpy(), wsum=wsum(W))
+    print("full-width text greedy ok:", tuple(out.shape), "rows stopped early:", stopped, "eos", eos)
+
+
+@torch.no_grad()
 def golden_siglip_crosscheck():
     """a13 / f2: timm is not installed, so the reference's own ``VisionTransformer`` class (siglip_vit.py) cannot be
     instantiated here and the SigLIP row stays PARITY UNPINNED.  What CAN be done: an independent implementation of the
@@ -497,6 +539,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "smallbatch":
         golden_small_batch()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "textfull":
+        golden_text_full_width()
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     golden_projector()
@@ -505,6 +550,7 @@ def main():
     golden_vq_full()
     golden_full_width()
     golden_small_batch()
+    golden_text_full_width()
     golden_text()
     golden_siglip_crosscheck()
 

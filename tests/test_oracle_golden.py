@@ -144,3 +144,19 @@ def test_smallbatch_long_fixture_oracle_reproduces_first_steps():
     toks, logits = R.sample_image(W, cfg, R.embed_tokens(W, ids), mask, 5.0, n_tokens=3, return_logits=True)
     assert np.array_equal(toks.numpy(), g["tokens"][:, :3])
     assert np.abs(logits[:, :, torch.from_numpy(g["vsel"]).long()].numpy() - g["sel_logits"][:3]).max() < 2e-3
+
+
+def test_text_fullwidth_fixture_is_consistent():
+    """generate_fullwidth.npz: left-padded prompts, several rows stop early and pad with the EOS id, the teacher-forced top-1 of the
+    un-stopped run is that run's own next token."""
+    g = load_golden("generate_fullwidth.npz")
+    ids, mask, out, probe, eos = g["ids"], g["mask"], g["out"], g["probe"], int(g["eos"])
+    assert ids.shape == (32, 128) and out.shape == (32, 40) and mask[0].all() and (mask.sum(1) >= 40).all()
+    assert ((mask[:, 1:] - mask[:, :-1]) >= 0).all()                           # left padding
+    stopped = (out == eos).any(1)
+    assert 2 <= stopped.sum() < 32
+    for r in np.nonzero(stopped)[0]:
+        k = int(np.argmax(out[r] == eos))
+        assert (out[r, k:] == eos).all() and (out[r, :k] == probe[r, :k]).all()      # same ids until the stop, EOS padding after it
+    live = np.cumsum(probe == 7, axis=1) == 0                                  # the probe run itself stops a row at the model's own EOS id (7)
+    assert live.mean() > 0.95 and np.array_equal(g["top_i"][..., 0].T[live], probe[live])
