@@ -448,6 +448,36 @@ def golden_text_full_width(B=32, L=128, N=40):
 
 
 @torch.no_grad()
+def golden_prefill_long(B=8, L=640):
+    """Long-context prefill at Janus-Pro-1B width (the mmu prompt shape: 576 image slots + text = 640 positions; also a long stage-1
+    prompt): 8 left-padded rows of 440..640 tokens, positions = attention_mask.cumsum - 1 (what GenerationMixin.generate feeds,
+    plangen_base.py:513-523), installed transformers LlamaModel.  5 120 packed tokens select the 256x256 GEMMs (incl. the RoPE
+    epilogue) and give the flash prefill kernel up to 10 key tiles / 5 query tiles per row."""
+    torch.set_num_threads(8)
+    cfg = R.OracleCfg(**FULLW)
+    W = R.make_weights(cfg, seed=3)
+    model = hf_llama(cfg, W)
+    g = torch.Generator().manual_seed(47)
+    prm = []
+    for b in range(B):
+        n = L if b == 0 else int(torch.randint(440, L + 1, (1,), generator=g))
+        row = torch.randint(8, cfg.vocab, (n,), generator=g).tolist()
+        row[0] = 1
+        prm.append(row)
+    ids, mask = R.pad_input_ids(prm, cfg.pad_id)
+    pos = (mask.long().cumsum(-1) - 1).clamp(min=0)
+    out = model(inputs_embeds=model.get_input_embeddings()(ids.long()), attention_mask=mask, position_ids=pos, use_cache=False).last_hidden_state
+    mine, _ = R.llama_forward(W, cfg, R.embed_tokens(W, ids), mask, pos)
+    real = mask.bool()
+    err = (out - mine)[real].abs().max().item()
+    assert err < 2e-3, err
+    pos_sel = sorted(set(list(range(0, L, 37)) + list(range(L - 6, L))))
+    np.savez_compressed(os.path.join(OUT, "prefill_long_fullwidth.npz"), ids=ids.numpy().astype(np.int16), pad=(L - mask.sum(-1)).numpy().astype(np.int32),
+                        pos_sel=np.array(pos_sel), hidden=out[:, pos_sel].numpy(), wsum=wsum(W))
+    print("long prefill ok; oracle-vs-transformers err", err, "pads", (L - mask.sum(-1)).tolist())
+
+
+@torch.no_grad()
 def golden_siglip_crosscheck():
     """a13 / f2: timm is not installed, so the reference's own ``VisionTransformer`` class (siglip_vit.py) cannot be
     instantiated here and the SigLIP row stays PARITY UNPINNED.  What CAN be done: an independent implementation of the
@@ -542,6 +572,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "textfull":
         golden_text_full_width()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "prefilllong":
+        golden_prefill_long()
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     golden_projector()
@@ -551,6 +584,7 @@ def main():
     golden_full_width()
     golden_small_batch()
     golden_text_full_width()
+    golden_prefill_long()
     golden_text()
     golden_siglip_crosscheck()
 

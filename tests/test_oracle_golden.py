@@ -160,3 +160,21 @@ def test_text_fullwidth_fixture_is_consistent():
         assert (out[r, k:] == eos).all() and (out[r, :k] == probe[r, :k]).all()      # same ids until the stop, EOS padding after it
     live = np.cumsum(probe == 7, axis=1) == 0                                  # the probe run itself stops a row at the model's own EOS id (7)
     assert live.mean() > 0.95 and np.array_equal(g["top_i"][..., 0].T[live], probe[live])
+
+
+def test_prefill_long_fixture_oracle_reproduces_a_row():
+    """prefill_long_fullwidth.npz: the oracle restatement on the shortest row (positions = mask.cumsum - 1) equals the stored
+    transformers hidden states; make_golden asserted all 8 rows at generation time."""
+    from fullwidth_cfg import FULLW
+    g = load_golden("prefill_long_fullwidth.npz")
+    pad = g["pad"]
+    assert g["ids"].shape == (8, 640) and pad[0] == 0 and pad.max() <= 200
+    r = int(np.argmax(pad))
+    cfg = R.OracleCfg(**FULLW)
+    W = R.make_weights(cfg, seed=3)
+    ids = torch.from_numpy(g["ids"][r:r + 1, pad[r]:].astype(np.int64)).int()
+    n = ids.shape[1]
+    hid, _ = R.llama_forward(W, cfg, R.embed_tokens(W, ids), torch.ones(1, n, dtype=torch.int64), torch.arange(n)[None])
+    sel = [(j, p - pad[r]) for j, p in enumerate(g["pos_sel"]) if p >= pad[r]]
+    err = max(np.abs(hid[0, q].numpy() - g["hidden"][r, j]).max() for j, q in sel)
+    assert err < 2e-3, err
