@@ -134,6 +134,36 @@ def golden_vq_full():
 
 
 @torch.no_grad()
+def golden_vq_full_encode():
+    """Full-size VQ-16 ENCODER + quantizer through the reference's own VQ_models['VQ-16'] (vq_model.py:494-498, :236-258): one 384^2
+    image (stored as uint8 so the input is exactly reproducible: x = u8 / 127.5 - 1) -> 576 code indices, with the distance gap between
+    the best and the second-best code of every token (a reduced-precision engine may differ only on near ties)."""
+    cfg = R.OracleCfg(n_layers=0, vocab=8)
+    W = R.make_weights(cfg, seed=4, with_lm_head=False, with_encoder=True)
+    m = ref_vq_module()
+    vq = m.VQ_models["VQ-16"]().eval()
+    missing = vq.load_state_dict(sub(W, "gen_vision_model."), strict=False)
+    assert all("codebook_used" in k for k in missing.missing_keys) and not missing.unexpected_keys, missing
+    g = torch.Generator().manual_seed(14)
+    # a smooth random field + noise, quantised to 8 bits
+    low = torch.nn.functional.interpolate(torch.rand(1, 3, 12, 12, generator=g), size=384, mode="bicubic", align_corners=False)
+    u8 = ((low + 0.15 * torch.randn(1, 3, 384, 384, generator=g)).clamp(0, 1) * 255).round().to(torch.uint8)
+    x = u8.float() / 127.5 - 1.0
+    quant, _, info = vq.encode(x)
+    idx = info[-1].reshape(-1)
+    mine = R.vq_encode(W, cfg, x).reshape(-1)
+    assert torch.equal(idx, mine)
+    h = vq.quant_conv(vq.encoder(x))
+    z = torch.nn.functional.normalize(h.permute(0, 2, 3, 1).reshape(-1, cfg.img_dim), dim=-1)
+    emb = torch.nn.functional.normalize(W["gen_vision_model.quantize.embedding.weight"], dim=-1)
+    d = (z ** 2).sum(1, keepdim=True) + (emb ** 2).sum(1) - 2 * z @ emb.t()
+    top2 = d.topk(2, dim=1, largest=False).values
+    np.savez_compressed(os.path.join(OUT, "vq_full_encode.npz"), image_u8=u8.numpy(), idx=idx.numpy().astype(np.int16),
+                        gap=(top2[:, 1] - top2[:, 0]).numpy(), wsum=wsum(sub(W, "gen_vision_model.")))
+    print("vq_full_encode ok; distinct codes", len(torch.unique(idx)), "median gap", float((top2[:, 1] - top2[:, 0]).median()))
+
+
+@torch.no_grad()
 def golden_projector():
     cfg = R.OracleCfg(**TINY)
     W = R.make_weights(cfg, seed=1)
@@ -572,6 +602,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "textfull":
         golden_text_full_width()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "vqenc":
+        os.makedirs(OUT, exist_ok=True)
+        golden_vq_full_encode()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "prefilllong":
         golden_prefill_long()
         return
@@ -581,6 +615,7 @@ def main():
     golden_vq_tiny()
     golden_llama_and_sampling()
     golden_vq_full()
+    golden_vq_full_encode()
     golden_full_width()
     golden_small_batch()
     golden_text_full_width()

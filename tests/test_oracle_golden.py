@@ -178,3 +178,14 @@ def test_prefill_long_fixture_oracle_reproduces_a_row():
     sel = [(j, p - pad[r]) for j, p in enumerate(g["pos_sel"]) if p >= pad[r]]
     err = max(np.abs(hid[0, q].numpy() - g["hidden"][r, j]).max() for j, q in sel)
     assert err < 2e-3, err
+
+
+def test_vq_full_encode_fixture_matches_oracle():
+    """vq_full_encode.npz comes from the reference's VQ_models['VQ-16'].encode; the oracle restatement gives the same 576 indices."""
+    g = load_golden("vq_full_encode.npz")
+    cfg = R.OracleCfg(n_layers=0, vocab=8)
+    W = R.make_weights(cfg, seed=4, with_lm_head=False, with_encoder=True)
+    assert abs(wsum({k: v for k, v in W.items() if k.startswith("gen_vision_model.")}) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    x = torch.from_numpy(g["image_u8"]).float() / 127.5 - 1.0
+    assert np.array_equal(R.vq_encode(W, cfg, x).reshape(-1).numpy(), g["idx"].astype(np.int64))
+    assert (g["gap"] >= 0).all() and len(np.unique(g["idx"])) > 300
