@@ -508,6 +508,52 @@ def golden_prefill_long(B=8, L=640):
 
 
 @torch.no_grad()
+def golden_full_depth(T=16):
+    """Janus-Pro-1B WIDTH AND DEPTH (24 layers, hidden 2048, 16 x 128 heads, MLP 5632; small embedding table): 2 CFG pairs, L = 64, T greedy
+    steps, transformers-driven like plangen_base.py:567-607.  What the 2-layer fixtures cannot show: error accumulation over 24 layers and the
+    per-layer strides of the KV cache / weight tables at the real depth."""
+    torch.set_num_threads(8)
+    cfg = R.OracleCfg(**dict(FULLW, n_layers=24))
+    W = R.make_weights(cfg, seed=6)
+    g = torch.Generator().manual_seed(53)
+    neg = torch.randint(8, cfg.vocab, (24,), generator=g).tolist(); neg[0] = 1
+    cond = []
+    for n in (64, 41):
+        row = torch.randint(8, cfg.vocab, (n,), generator=g).tolist(); row[0] = 1
+        cond.append(row)
+    ids, mask = R.t2i_infer_collate_batch(cond, neg, cfg.pad_id, cfg.img_tokens)
+    model = hf_llama(cfg, W)
+    inputs_embeds = model.get_input_embeddings()(ids.long())
+    tokens = torch.zeros((2, T), dtype=torch.int)
+    logits_all, outputs = [], None
+    for i in range(T):
+        outputs = model(inputs_embeds=inputs_embeds, attention_mask=mask, use_cache=True, past_key_values=outputs.past_key_values if i != 0 else None)
+        h_last = outputs.last_hidden_state[:, -1, :]
+        if i == 0:
+            prefill_last = h_last.clone()
+        logits = R.gen_head(W, h_last)
+        logits = logits[1::2] + 5.0 * (logits[0::2] - logits[1::2])
+        logits_all.append(logits.clone())
+        nxt = torch.argmax(logits, dim=-1, keepdim=True)
+        tokens[:, i] = nxt.squeeze(-1)
+        nxt = torch.cat([nxt.unsqueeze(1), nxt.unsqueeze(1)], dim=1).view(-1)
+        inputs_embeds = R.prepare_gen_img_embeds(W, nxt).unsqueeze(1)
+    logits_all = torch.stack(logits_all)                             # [T, 2, V]
+    mine_tok, mine_logits = R.sample_image(W, cfg, R.embed_tokens(W, ids), mask, 5.0, n_tokens=T, return_logits=True)
+    assert torch.equal(mine_tok, tokens)
+    err = (mine_logits - logits_all).abs().max().item()
+    assert err < 5e-3, err
+    gv = torch.Generator().manual_seed(59)
+    vsel = torch.randperm(cfg.img_vocab, generator=gv)[:256].sort().values
+    tv, ti = logits_all.topk(4, dim=-1)
+    L = ids.shape[1]
+    np.savez_compressed(os.path.join(OUT, "sample_image_fulldepth.npz"), ids=ids.numpy().astype(np.int16), pad=(L - mask[:, :L].sum(-1)).numpy().astype(np.int32),
+                        tokens=tokens.numpy(), top_v=tv.numpy(), top_i=ti.numpy().astype(np.int32), vsel=vsel.numpy().astype(np.int32),
+                        sel_logits=logits_all[:, :, vsel].numpy(), prefill_last=prefill_last.numpy(), wsum=wsum(W))
+    print("full-depth sample_image ok; oracle-vs-transformers logits err", err, "logit std", float(logits_all.std()))
+
+
+@torch.no_grad()
 def golden_siglip_crosscheck():
     """a13 / f2: timm is not installed, so the reference's own ``VisionTransformer`` class (siglip_vit.py) cannot be
     instantiated here and the SigLIP row stays PARITY UNPINNED.  What CAN be done: an independent implementation of the
@@ -606,6 +652,9 @@ def main():
         os.makedirs(OUT, exist_ok=True)
         golden_vq_full_encode()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "fulldepth":
+        golden_full_depth()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "prefilllong":
         golden_prefill_long()
         return
@@ -620,6 +669,7 @@ def main():
     golden_small_batch()
     golden_text_full_width()
     golden_prefill_long()
+    golden_full_depth()
     golden_text()
     golden_siglip_crosscheck()
 

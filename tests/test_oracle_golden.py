@@ -189,3 +189,9 @@ def test_vq_full_encode_fixture_matches_oracle():
     x = torch.from_numpy(g["image_u8"]).float() / 127.5 - 1.0
     assert np.array_equal(R.vq_encode(W, cfg, x).reshape(-1).numpy(), g["idx"].astype(np.int64))
     assert (g["gap"] >= 0).all() and len(np.unique(g["idx"])) > 300
+
+
+def test_fulldepth_fixture_is_consistent():
+    g = load_golden("sample_image_fulldepth.npz")
+    assert g["ids"].shape == (4, 64) and g["tokens"].shape == (2, 16) and (g["ids"][1, g["pad"][1]:] == g["ids"][3, g["pad"][3]:]).all()
+    assert np.array_equal(g["top_i"][..., 0].T, g["tokens"]) and (g["top_v"][..., 0] >= g["top_v"][..., 1]).all()
