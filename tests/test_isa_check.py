@@ -21,7 +21,8 @@ def test_lds_dma_protocols_match_the_compiled_code():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
     out = p.stdout
     assert out.strip().endswith("0 failed")
-    assert out.count("fifo protocol holds in the strict form") >= 3           # flash2 + two gemm256 instantiations
+    assert out.count("fifo protocol holds in the strict form") >= 4           # flash2 + three gemm256 instantiations (plain, RoPE epilogue, conv)
     assert out.count("weight ring strict") == 2                               # production halo convolution (plain + upsample)
+    assert out.count("weak form holds") == 2                                  # the 128x128 GEMM (plain / implicit-im2col loaders): same-phase form, kept knowingly
     sk4 = [l for l in out.splitlines() if l.startswith("sk4:")][0]
     assert "0 failed" in sk4 and int(sk4.split()[1]) >= 40                    # production + bench instantiations of the decode GEMM
