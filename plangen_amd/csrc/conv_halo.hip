@@ -136,6 +136,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
                     // W tile t (and, for t == 0, the halo) has landed: the loads issued after it are tiles t+1, t+2
                     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     asm volatile("s_barrier" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");                    // round 3: retirement and first read one barrier apart (staging rule, strict form)
                     stage_w(t + 3);                                            // slot of tile t-1: every wave is past its reads
                 }
                 const char* ws = wlds + (t & 3) * CH_WSLOT;
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(512) void conv3x3_out_halo_kernel(const bf16* __res
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        __builtin_amdgcn_s_barrier();                      // round 3: the patch is retired by the barrier above and read one barrier later (staging rule, strict form)
         f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {

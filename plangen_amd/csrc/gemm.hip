@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __r
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
@@ -108,6 +109,9 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(AL al, const bf16* __r
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // Round 3: tile kt+1 was retired by the wait + barrier above; a second barrier separates that retirement from the phase that reads it
+        // (the staging rule of tools/dma_isa_check.py, strict form -- a third LDS slot would halve this kernel's residency instead).
+        __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
     // C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg

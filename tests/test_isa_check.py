@@ -22,7 +22,10 @@ def test_lds_dma_protocols_match_the_compiled_code():
     out = p.stdout
     assert out.strip().endswith("0 failed")
     assert out.count("fifo protocol holds in the strict form") >= 4           # flash2 + three gemm256 instantiations (plain, RoPE epilogue, conv)
-    assert out.count("weight ring strict") == 2                               # production halo convolution (plain + upsample)
-    assert out.count("weak form holds") == 2                                  # the 128x128 GEMM (plain / implicit-im2col loaders): same-phase form, kept knowingly
+    assert out.count(": weight ring strict") == 2                             # production (staggered) halo convolution, plain + upsample
+    assert out.count("double buffer, strict form holds") == 2                 # the 128x128 GEMM (plain / implicit-im2col loaders), two barriers per K tile
+    assert out.count("lock-step weight ring strict") == 2                     # conv_halo=2 option kernels
+    assert out.count("patch retired") == 1                                    # conv_out halo kernel
+    assert "weak" not in out and "legacy" not in out                          # no LDS-DMA kernel is left on the same-phase form
     sk4 = [l for l in out.splitlines() if l.startswith("sk4:")][0]
     assert "0 failed" in sk4 and int(sk4.split()[1]) >= 40                    # production + bench instantiations of the decode GEMM

@@ -15,8 +15,8 @@ have a spec below (a new LDS-DMA kernel without one fails the check):
           tile of the stream in loop iteration i.  Checked per read: the tile was retired as of the barrier BEFORE the most
           recent one (strict form), and per DMA: the tile that last lived in its slot was read before an earlier barrier.
   sk4     gemm_sk4_kernel: tools/sk4_isa_check.py (own walker: W register ring + x ring share one vmcnt counter).
-  legacy  same-phase protocol kept knowingly (listed with the reason); the 128x128 GEMM is replayed against the weak form
-          (wait -> barrier -> read, slot re-staged behind a barrier), option-only / probe kernels are listed.
+  big / halo_lock / halo_stag / once / probe: per-kernel replays of the same rule (128x128 GEMM, the halo convolution's two wave schedules),
+          the conv_out halo (staged once per tile) and the measurement probe are listed.
 
 usage: dma_isa_check.py            (compiles plangen_amd/csrc/*.hip with -S into /tmp/dma_isa/)"""
 import os, re, subprocess, sys
@@ -154,14 +154,13 @@ SPECS = [
     ("gemm256", r"gemm256_kernel", dict(kind="fifo", g=2, need=None, tile_cls=lambda n: n & 3, slot_reuse=lambda c: 8, strict=True,
                                         why="half-tiles retired by vmcnt(8) in the phase before they are read; two barriers per phase")),
     ("gemm", r"gemm_sk4_kernel", dict(kind="sk4")),
-    ("gemm", r"gemm_big_kernel", dict(kind="legacy", why="128x128 double buffer: vmcnt(0) + __syncthreads, next tile read in the phase that barrier opens; "
-                                      "a third slot would halve its residency (96 KiB).  Not on the bench path's dominant shapes; cold-stressed "
-                                      "(tools/op_cold_stress.py, tests/test_gpu_ops.py cold tests)")),
+    ("gemm", r"gemm_big_kernel", dict(kind="big", why="128x128 double buffer: vmcnt(0) + barrier retire tile t+1, a second barrier opens the phase that reads it "
+                                      "(round 3; a third LDS slot would halve the kernel's residency, the extra barrier measured free)")),
     ("conv_halo", r"conv3x3_halo_kernelI.*Lb1ELb[01]E", dict(kind="halo_stag", why="production: 4-slot weight ring, W(t+1) retired by vmcnt(2) in phase t and read in phase t+1; "
                                                              "halo + W(0) retired two barriers before the first read")),
-    ("conv_halo", r"conv3x3_halo_kernelI.*Lb0ELb[01]E", dict(kind="legacy", why="conv_halo=2 option (not the default): vmcnt(4) + barrier, tile read in the phase that barrier opens")),
+    ("conv_halo", r"conv3x3_halo_kernelI.*Lb0ELb[01]E", dict(kind="halo_lock", why="conv_halo=2 option (lock-step waves): vmcnt(4) + two barriers per K tile")),
     ("bench_kernels", r"dma_order_kernel", dict(kind="probe", why="measurement probe (tools/dma_order_probe.py), not on the product path")),
-    ("conv_halo", r"conv3x3_out_halo_kernel", dict(kind="once", why="halo patch staged once per tile: vmcnt(0) + barrier, then a second barrier-separated phase reads it")),
+    ("conv_halo", r"conv3x3_out_halo_kernel", dict(kind="once", why="halo patch staged once per tile (conv_out, 128 -> 3 channels)")),
 ]
 
 
@@ -222,8 +221,22 @@ def main():
                     report.append(f"FAIL {fname}:{short}: " + ("; ".join(errs[:3]) if errs else f"prologue: {nbar} barrier(s) between the retiring vmcnt(2) and the first read, {nj} halo DMAs"))
                 else:
                     report.append(f"ok   {fname}:{short}: weight ring strict over 6 replayed iterations; halo ({nj} DMAs) + W(0) retired {nbar} barriers before the first read")
-            elif spec["kind"] == "legacy" and "gemm_big_kernel" in name:
-                # weak form only (wait -> barrier -> read, slot re-staged behind a barrier): tile t+1 is staged while tile t is read
+            elif spec["kind"] == "halo_lock":
+                pro, body = main_loop(ev)
+                state = {"n": 0}
+
+                def need(i, cls, state=state):
+                    t = state["n"] // 16; state["n"] += 1
+                    return 1 + t
+                synth = [("dma", None)] * 8                                  # halo as one 2-instruction group + W0, W1, W2
+                errs, n = (["no main loop found"], 0) if body is None else replay(synth, body, dict(g=2, need=need, tile_cls=lambda n: 1 if n else 0,
+                                                                                                    slot_reuse=lambda c: 4 if c else 10 ** 6, strict=True))
+                if errs:
+                    bad += 1; report.append(f"FAIL {fname}:{short}: " + "; ".join(errs[:3]))
+                else:
+                    report.append(f"ok   {fname}:{short}: lock-step weight ring strict over 6 replayed iterations -- {spec['why']}")
+            elif spec["kind"] == "big":
+                # stage(t+1) | read tile t | vmcnt(0) + barrier (retires t+1) | barrier
                 pro, body = main_loop(ev)
                 if body is not None:
                     kinds = [k for k, _ in body]
@@ -231,12 +244,25 @@ def main():
                         k = kinds.index("dma")                  # hipcc rotated the loop (stage(t+1) sits behind the back edge's target and the
                         body = body[k:] + body[:k]              # prologue jumps into it): replay in execution order -- stage(t+1), read tile t, wait, barrier
                 errs, n = (["no main loop found"], 0) if body is None else replay(pro, body, dict(g=8, need=lambda i, cls: i if cls == "ds_read_b128" else None,
-                                                                                              tile_cls=lambda n: 0, slot_reuse=lambda c: 2, strict=False))
+                                                                                              tile_cls=lambda n: 0, slot_reuse=lambda c: 2, strict=True))
                 if errs:
                     bad += 1
                     report.append(f"FAIL {fname}:{short}: " + "; ".join(errs[:3]))
                 else:
-                    report.append(f"weak {fname}:{short}: same-phase form kept knowingly, weak form holds ({n} DMA instructions replayed) -- {spec['why']}")
+                    report.append(f"ok   {fname}:{short}: double buffer, strict form holds ({n} DMA instructions replayed) -- {spec['why']}")
+            elif spec["kind"] == "once":
+                # per tile: fill (DMA) -> vmcnt(0) -> barrier -> barrier -> fragment reads -> barrier (patch free).  Linear walk of the tile loop.
+                flat = [e for e in ev if e[0] in ("dma", "wait", "bar", "read")]
+                last_dma = max(k for k, e in enumerate(flat) if e[0] == "dma")
+                first_read = next(k for k, e in enumerate(flat) if e[0] == "read" and k > last_dma)
+                between = flat[last_dma + 1:first_read]
+                w0 = [k for k, e in enumerate(between) if e == ("wait", 0)]
+                nbar = sum(1 for e in between[w0[-1]:] if e[0] == "bar") if w0 else 0
+                after = flat[first_read:]
+                if not w0 or nbar < 2 or not any(e[0] == "bar" for e in after):
+                    bad += 1; report.append(f"FAIL {fname}:{short}: {nbar} barrier(s) between the retiring vmcnt(0) and the first read of the patch")
+                else:
+                    report.append(f"ok   {fname}:{short}: patch retired {nbar} barriers before its first read, released by a barrier after the last -- {spec['why']}")
             else:
                 report.append(f"note {fname}:{short}: {spec['kind']} -- {spec['why']}")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sk4_isa_check.py"), os.path.join(OUT, "gemm.s")], capture_output=True, text=True)
