@@ -117,6 +117,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--time-stride", type=int, default=8, help="instrumented pass: time every n-th decode step")
     ap.add_argument("--opt", action="append", default=[], help="engine tuning option key=value (pg_set_option)")
+    ap.add_argument("--no-rccl-selftest", action="store_true", help="N=1: skip the one-rank RCCL self-test child run after the timed region")
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher dry run (no GPU): every rank checks its env, joins a gloo group, all-reduces, rank 0 prints JSON")
     return ap.parse_args(argv)
@@ -137,17 +138,35 @@ def spawn_ranks(n, argv, poll_s=0.2, grace_s=5.0):
     non-zero exit the others are terminated (SIGTERM, SIGKILL after ``grace_s``) and the launcher returns non-zero at once --
     a rank that dies before a collective would otherwise leave the survivors in RCCL until the watchdog fires (minutes)."""
     import tempfile
-    import threading
     port = os.environ.get("MASTER_PORT") or str(free_port())
     procs = []
     out0 = tempfile.TemporaryFile()
+
+    # The ranks live in their own sessions, so a signal to the launcher's process group does not reach them.  Python's default
+    # SIGTERM / SIGHUP action would kill the launcher without unwinding and leave the ranks holding the GPUs (ADVICE r3): turn
+    # both into an exception so the kill path below runs.  Second line of defence: every rank asks the kernel to SIGTERM it
+    # when its parent dies (PR_SET_PDEATHSIG), which also covers a SIGKILLed launcher.
+    class _Terminated(BaseException):
+        pass
+
+    def _on_signal(signum, frame):
+        raise _Terminated(signum)
+    old_handlers = {sg: signal.signal(sg, _on_signal) for sg in (signal.SIGTERM, signal.SIGHUP)}
+
+    def _pdeathsig():
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+        except Exception:
+            pass
+
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PG_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=out0 if r == 0 else None, start_new_session=True))
+                                      stdout=out0 if r == 0 else None, start_new_session=True, preexec_fn=_pdeathsig))
     rcs = [None] * n
     failed = None
     interrupted = False
@@ -184,7 +203,11 @@ def spawn_ranks(n, argv, poll_s=0.2, grace_s=5.0):
                 p.wait()
         rcs = [p.returncode for p in procs]
         if interrupted:
+            for sg, h in old_handlers.items():
+                signal.signal(sg, h)
             return 130
+    for sg, h in old_handlers.items():
+        signal.signal(sg, h)
     out0.seek(0)
     sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
@@ -209,6 +232,11 @@ def launch_check(args, world, rank):
     if die is not None and int(die) == rank:
         sys.stderr.write(f"bench.py: rank {rank} dying on request (PG_TEST_DIE_RANK)\n")
         os._exit(7)
+    hang = os.environ.get("PG_TEST_HANG_S")                 # test hook: every rank reports its pid, then sleeps (launcher-signal test)
+    if hang is not None:
+        with open(os.path.join(os.environ["PG_TEST_PID_DIR"], f"rank{rank}.pid"), "w") as f:
+            f.write(str(os.getpid()))
+        time.sleep(float(hang))
     t = torch.tensor([float(rank + 1)])
     if world > 1:
         dist.all_reduce(t)
@@ -445,12 +473,46 @@ def run_rank(args):
         # 16 threads: measured fastest for these small torch-CPU GEMMs on the 256-core bench host
         # (ms/step: 16 thr 89, 32 thr 144, 64 thr 298, 256 thr 42 466)
         out["cpu_baseline"] = cpu_baseline(L, args.cpu_steps, min(args.cpu_threads, os.cpu_count() or 1))
+    if rank == 0 and world == 1 and not args.no_rccl_selftest and not args.tiny:
+        out["rccl_selftest"] = rccl_selftest()
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
     return 0
+
+
+def rccl_selftest(timeout_s=180):
+    """N = 1 only, after the timed region: a ONE-RANK RCCL communicator in a fresh child process (tests/helpers/rccl_one_rank.py: the
+    broadcast / gather / all_gather / barrier of plangen_amd/dist.py on device tensors beside a tiny engine).  A single GPU cannot measure
+    the scaling curve; this records, in the driver's own bench line, that librccl initialises and the path's collectives execute on this
+    box.  Failure or timeout is REPORTED, never fatal: the N = 1 number does not depend on RCCL."""
+    import json as _json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_one_rank.py"), "nccl"], env=env,
+                           capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode == 0 and lines:
+            return _json.loads(lines[-1])
+        return {"rccl_one_rank": "failed", "rc": p.returncode, "stderr_tail": p.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"rccl_one_rank": "timeout", "timeout_s": timeout_s}
+    except Exception as ex:                                   # noqa: BLE001 -- reported in the line
+        return {"rccl_one_rank": "failed", "error": repr(ex)[:300]}
+
+
+def visible_gpus():
+    """Device count from a THROW-AWAY child (the launcher itself must stay free of any GPU / HIP state); None when it cannot tell."""
+    try:
+        p = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+        return int(p.stdout.strip().splitlines()[-1])
+    except Exception:                                          # noqa: BLE001
+        return None
 
 
 def kernel_src_sha():
@@ -468,6 +530,12 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # parent: start N fresh rank processes; no torch.cuda / HIP call has happened in this process
+        if not args.launch_check and os.environ.get("PG_FORCE_DEVICE") is None:
+            n = visible_gpus()
+            if n is not None and n < args.gpus:
+                sys.stderr.write(f"bench.py: --gpus {args.gpus} but this box exposes {n} GPU(s) (torch.cuda.device_count() in a child process); "
+                                 "not starting ranks that would die with 'invalid device ordinal'\n")
+                return 2
         return spawn_ranks(args.gpus, argv)
     return run_rank(args)
 

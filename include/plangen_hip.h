@@ -16,7 +16,9 @@
  *   - the library owns weights, KV cache and workspaces (hipMalloc at pg_create).
  *   - every call is asynchronous on the caller's hipStream_t; no hidden device syncs
  *     except where stated (pg_generate_text_greedy polls its finished-flag; pg_prefill reads ONE
- *     4-byte flag back when it probes for a batch-constant negative prompt).
+ *     4-byte flag back when it probes for a batch-constant negative prompt -- ONLY when the caller
+ *     did not supply the answer through the one-shot ``uncond_shared_hint`` option (0 / 1): with
+ *     the hint set, pg_prefill performs no device->host read and no stream synchronisation).
  *   - one handle per (process, GPU); a handle is not thread-safe.
  */
 #ifndef PLANGEN_HIP_H
@@ -222,7 +224,8 @@ int pg_set_option(pg_handle h, const char* key, int64_t value);
 /* Bytes of device memory the handle owns (weights + KV + workspace). */
 int64_t pg_device_bytes(pg_handle h);
 /* Debug taps for parity tests: copy an internal buffer to dst_dev.
- * name: "kcache"/"vcache" (layer in ``index``), "x" (residual stream), "xn". */
+ * name: "kcache"/"vcache" (layer in ``index``), "x" (residual stream), "xn", "hfin", "gen_table", "pq_table", "qbuf", "obuf",
+ * "vit_feat" (SigLIP features of the last pg_vision_encode, after the final LayerNorm, compute dtype [B, P, vit_width]). */
 int pg_debug_read(pg_handle h, const char* name, int index, void* dst_dev, int64_t max_bytes, pg_stream s);
 
 /* Stand-alone operator entry points (unit parity tests call these through the ABI;

@@ -477,6 +477,55 @@ def golden_text_full_width(B=32, L=128, N=40):
     print("full-width text greedy ok:", tuple(out.shape), "rows stopped early:", stopped, "eos", eos)
 
 
+FULLV = dict(FULLW, vocab=102400, eos_id=100001, pad_id=100002)
+
+
+@torch.no_grad()
+def golden_text_full_vocab(B=12, L=96, N=12):
+    """a11 at the REAL vocabulary (round 4): Janus-Pro-1B width on 2 layers with vocab 102 400 (lm_head 2048 -> 102 400, 419 MB in bf16;
+    `text_scan_kernel` in 16 chunks of 6 400 columns), 12 left-padded prompts of 24..96 tokens, 12 greedy steps of
+    ``LlamaForCausalLM.generate`` driven like plangen_base.py:513-523.  The EOS id is chosen from a probe run among ids >= 65 536 (the
+    real EOS is 100 001: ids do not fit 16 bits) so that at least one row stops early.  ids stored as int32."""
+    torch.set_num_threads(8)
+    cfg = R.OracleCfg(**FULLV)
+    W = R.make_weights(cfg, seed=11)
+    lm = hf_llama(cfg, W, causal_lm=True)
+    g = torch.Generator().manual_seed(47)
+    prm = []
+    for b in range(B):
+        n = L if b == 0 else int(torch.randint(24, L + 1, (1,), generator=g))
+        row = torch.randint(8, 100000, (n,), generator=g).tolist()
+        row[0] = 1
+        prm.append(row)
+    ids, mask = R.pad_input_ids(prm, cfg.pad_id)
+    emb = lm.get_input_embeddings()(ids.long())
+    probe = lm.generate(inputs_embeds=emb, attention_mask=mask, pad_token_id=cfg.eos_id, bos_token_id=1, eos_token_id=cfg.eos_id,
+                        max_new_tokens=N, do_sample=False, use_cache=True)
+    assert probe.shape == (B, N) and not (probe == cfg.eos_id).any()
+    mid = probe[:, 3:N - 2]
+    cands = [int(t) for t in mid.reshape(-1).unique() if int(t) >= 65536]
+    assert cands, "no generated id >= 65536 in the probe"
+    rows_with = [int((mid == t).any(1).sum()) for t in cands]
+    eos = cands[int(np.argmax(rows_with))]
+    out = lm.generate(inputs_embeds=emb, attention_mask=mask, pad_token_id=eos, bos_token_id=1, eos_token_id=eos,
+                      max_new_tokens=N, do_sample=False, use_cache=True)
+    mine = R.generate_text_greedy(W, cfg, R.embed_tokens(W, ids), mask, N, eos)
+    assert torch.equal(out, mine), (out.shape, mine.shape)
+    stopped = int(((out == eos).any(1)).sum())
+    assert 1 <= stopped < B, stopped
+    _, logits = R.generate_text_greedy(W, cfg, R.embed_tokens(W, ids), mask, N, cfg.eos_id, min_new_tokens=N, force_tokens=probe, return_logits=True)
+    gv = torch.Generator().manual_seed(53)
+    vsel = torch.cat([torch.randperm(cfg.vocab, generator=gv)[:120], torch.tensor([0, 6399, 6400, 65535, 65536, 95999, 96000, 102399])]).unique()
+    tv, ti = logits.topk(2, dim=-1)
+    chunks = sorted(set((probe.reshape(-1) // 6400).tolist()))
+    np.savez_compressed(os.path.join(OUT, "generate_fullvocab.npz"), ids=ids.numpy().astype(np.int32), mask=mask.numpy().astype(np.int8),
+                        eos=eos, out=out.numpy().astype(np.int32), probe=probe.numpy().astype(np.int32), top_v=tv.numpy(), top_i=ti.numpy().astype(np.int32),
+                        vsel=vsel.numpy().astype(np.int32), sel_logits=logits[:, :, vsel].numpy(), wsum=wsum(W))
+    print("full-vocabulary text greedy ok:", tuple(out.shape), "rows stopped early:", stopped, "eos", eos, "ids >= 65536:",
+          int((probe >= 65536).sum()), "of", probe.numel(), "argmax chunks hit:", len(chunks), "of 16; top-1 margin p50",
+          float((tv[..., 0] - tv[..., 1]).median()))
+
+
 @torch.no_grad()
 def golden_prefill_long(B=8, L=640):
     """Long-context prefill at Janus-Pro-1B width (the mmu prompt shape: 576 image slots + text = 640 positions; also a long stage-1
@@ -599,6 +648,202 @@ def golden_siglip_crosscheck():
     print("siglip cross-check ok; oracle vs transformers.SiglipVisionModel err", err)
 
 
+# --------------------------------------------------------------------------- SigLIP at production shape (round 4)
+VISW = dict(hidden=2048, inter=512, n_layers=1, n_heads=16, head_dim=128, vocab=512,
+            img_vocab=256, img_dim=8, grid=8, gen_head_dim=256, vq_ch=64,
+            vq_ch_mult=(1, 2, 2), vq_z=64, eos_id=7, pad_id=3,
+            vit_width=1024, vit_layers=2, vit_heads=16, vit_mlp=4096, vit_patch=16, vit_img=384)
+
+
+def _timm_standins():
+    """LABELLED STAND-INS for the two timm modules siglip_vit.py imports (timm is not installed and there is no network).
+    They exist only so that the REFERENCE's own ``Attention`` / ``Block`` / ``VisionTransformer.forward_features`` /
+    ``create_siglip_vit`` (siglip_vit.py:136-192, :209-256, :562-572, :641-671) and ``CLIPVisionTower.forward``
+    (clip_encoder.py:107-122) execute here.  What is NOT the reference / timm's code: ``PatchEmbed`` (Conv2d k = s = patch,
+    flatten(2).transpose(1, 2) -- timm's documented behaviour with flatten=True, norm_layer=None) and ``Mlp`` (fc1 -> act -> fc2,
+    timm's attribute names so the checkpoint keys match); DropPath / PatchDropout are never constructed at rate 0,
+    AttentionPoolLatent is built by global_pool='map' and removed again by plangen_base.py:105-106 before any forward.
+    The row therefore stays PARITY UNPINNED (two trivial modules are stand-ins); everything else that runs is reference code."""
+    import typing
+    import torch.nn as nn
+
+    class PatchEmbed(nn.Module):
+        def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, bias=True, dynamic_img_pad=False, **kw):
+            super().__init__()
+            assert not kw and not dynamic_img_pad
+            self.grid_size = (img_size // patch_size, img_size // patch_size)
+            self.num_patches = self.grid_size[0] * self.grid_size[1]
+            self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
+
+        def forward(self, x):
+            return self.proj(x).flatten(2).transpose(1, 2)
+
+    class Mlp(nn.Module):
+        def __init__(self, in_features, hidden_features=None, act_layer=nn.GELU, drop=0.0):
+            super().__init__()
+            assert drop == 0.0
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features, in_features)
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+    class AttentionPoolLatent(nn.Module):          # constructed by global_pool='map', deleted before use (plangen_base.py:105-106)
+        def __init__(self, *a, **kw):
+            super().__init__()
+
+    class _Never(nn.Module):
+        def __init__(self, *a, **kw):
+            raise AssertionError("DropPath / PatchDropout are not constructed at rate 0")
+
+    def _never(*a, **kw):
+        raise AssertionError("not on the inference path")
+
+    tl = types.ModuleType("timm.layers")
+    tl.AttentionPoolLatent, tl.DropPath, tl.PatchDropout, tl.Mlp, tl.PatchEmbed = AttentionPoolLatent, _Never, _Never, Mlp, PatchEmbed
+    tl.LayerType, tl.resample_abs_pos_embed = typing.Any, _never
+    tm = types.ModuleType("timm.models._manipulate")
+    tm.checkpoint_seq, tm.named_apply = _never, _never
+    timm, tmm = types.ModuleType("timm"), types.ModuleType("timm.models")
+    timm.layers, timm.models, tmm._manipulate = tl, tmm, tm
+    return {"timm": timm, "timm.layers": tl, "timm.models": tmm, "timm.models._manipulate": tm}
+
+
+def ref_siglip_modules():
+    """siglip_vit.py and clip_encoder.py of the reference, imported by file path with the stand-ins above (and an empty
+    ``torchvision.transforms``, used only when pixel_mean / pixel_std are given -- Janus-Pro passes none)."""
+    saved = {k: sys.modules.get(k) for k in ("timm", "timm.layers", "timm.models", "timm.models._manipulate", "torchvision",
+                                             "torchvision.transforms", "janus", "janus.models", "janus.models.siglip_vit")}
+    sys.modules.update(_timm_standins())
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+    tv.transforms = tvt
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt})
+    try:
+        sv = _load("ref_siglip_vit", os.path.join(REF, "siglip_vit.py"))
+        j, jm = types.ModuleType("janus"), types.ModuleType("janus.models")
+        j.models, jm.siglip_vit = jm, sv
+        sys.modules.update({"janus": j, "janus.models": jm, "janus.models.siglip_vit": sv})
+        ce = _load("ref_clip_encoder", os.path.join(REF, "clip_encoder.py"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return sv, ce
+
+
+def _load_vit_weights(vt, W, cfg):
+    VT = "vision_model.vision_tower."
+    sd = {k[len(VT):]: v for k, v in W.items() if k.startswith(VT)}
+    r = vt.load_state_dict(sd, strict=True)
+    assert not r.missing_keys and not r.unexpected_keys, r
+    assert len(vt.blocks) == cfg.vit_layers
+
+
+def _hf_siglip(cfg, W):
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    hc = SiglipVisionConfig(hidden_size=cfg.vit_width, intermediate_size=cfg.vit_mlp, num_hidden_layers=cfg.vit_layers,
+                            num_attention_heads=cfg.vit_heads, num_channels=3, image_size=cfg.vit_img, patch_size=cfg.vit_patch,
+                            hidden_act="gelu", layer_norm_eps=1e-6, attention_dropout=0.0, vision_use_head=False)
+    m = SiglipVisionModel(hc).eval()
+    VT = "vision_model.vision_tower."
+    sd = {"vision_model.embeddings.patch_embedding.weight": W[VT + "patch_embed.proj.weight"],
+          "vision_model.embeddings.patch_embedding.bias": W[VT + "patch_embed.proj.bias"],
+          "vision_model.embeddings.position_embedding.weight": W[VT + "pos_embed"][0],
+          "vision_model.post_layernorm.weight": W[VT + "norm.weight"], "vision_model.post_layernorm.bias": W[VT + "norm.bias"]}
+    Cw = cfg.vit_width
+    for i in range(cfg.vit_layers):
+        b, h = f"{VT}blocks.{i}.", f"vision_model.encoder.layers.{i}."
+        qkv_w, qkv_b = W[b + "attn.qkv.weight"], W[b + "attn.qkv.bias"]
+        for j, nm in enumerate(("q_proj", "k_proj", "v_proj")):          # timm packs q|k|v rows (siglip_vit.py:164-176)
+            sd[h + f"self_attn.{nm}.weight"] = qkv_w[j * Cw:(j + 1) * Cw]
+            sd[h + f"self_attn.{nm}.bias"] = qkv_b[j * Cw:(j + 1) * Cw]
+        sd[h + "self_attn.out_proj.weight"], sd[h + "self_attn.out_proj.bias"] = W[b + "attn.proj.weight"], W[b + "attn.proj.bias"]
+        for a_, b_ in (("layer_norm1", "norm1"), ("layer_norm2", "norm2")):
+            sd[h + a_ + ".weight"], sd[h + a_ + ".bias"] = W[b + b_ + ".weight"], W[b + b_ + ".bias"]
+        for a_ in ("fc1", "fc2"):
+            sd[h + f"mlp.{a_}.weight"], sd[h + f"mlp.{a_}.bias"] = W[b + f"mlp.{a_}.weight"], W[b + f"mlp.{a_}.bias"]
+    if not any(k.startswith("vision_model.") for k in m.state_dict()):          # transformers >= 5: no wrapper prefix
+        sd = {k[len("vision_model."):]: v for k, v in sd.items()}
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all("position_ids" in k for k in missing.missing_keys), missing
+    return m
+
+
+def siglip_fullwidth_images(cfg, n=2, seed=41):
+    """Seeded inputs of the production-shape fixture: uniform(-1, 1) with a smooth per-image structure (a few low-frequency
+    waves) so attention rows are not near-uniform.  Regenerated by the GPU test from the same seed (3.5 MB not committed)."""
+    g = torch.Generator().manual_seed(seed)
+    S = cfg.vit_img
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, S), torch.linspace(0, 1, S), indexing="ij")
+    img = torch.rand(n, 3, S, S, generator=g) * 2 - 1
+    for i in range(n):
+        for c in range(3):
+            f = torch.rand(4, generator=g) * 6 + 1
+            img[i, c] = 0.5 * img[i, c] + 0.5 * torch.sin(f[0] * yy * 3.1 + f[1]) * torch.cos(f[2] * xx * 2.7 + f[3])
+    return img.clamp(-1, 1)
+
+
+@torch.no_grad()
+def golden_siglip_fullwidth():
+    """a13 / f2 at the PRODUCTION SHAPE of the SigLIP-L tower (siglip_vit.py:628-637: width 1024, 16 heads x 64, MLP 4096,
+    patch 16, 384^2 -> 576 tokens) on 2 layers, 2 images.  Three implementations must agree before anything is stored:
+      (1) the REFERENCE's own siglip_vit.py classes -- create_siglip_vit('siglip_large_patch16_384', select_layer=2) inside the
+          reference's CLIPVisionTower (clip_encoder.py), attn_pool removed as plangen_base.py:105-106 -- with labelled
+          stand-ins for timm's PatchEmbed / Mlp (see _timm_standins);
+      (2) transformers.SiglipVisionModel (independent third-party implementation);
+      (3) oracle.siglip_forward.
+    Stored: a strided token subset of the features and of aligner(features), plus the tiny-shape features from (1)."""
+    cfg = R.OracleCfg(**VISW)
+    W = R.make_weights(cfg, seed=7, with_vision=True)
+    img = siglip_fullwidth_images(cfg)
+    sv, ce = ref_siglip_modules()
+    tower = ce.CLIPVisionTower(model_name="siglip_large_patch16_384", image_size=cfg.vit_img, select_feature="same",
+                               select_layer=cfg.vit_layers).eval()       # select_layer > 0 -> depth = min(24, select_layer)
+    assert isinstance(tower.vision_tower, sv.VisionTransformer) and tower.vision_tower.ignore_head
+    tower.vision_tower.attn_pool = None                                  # plangen_base.py:105-106
+    _load_vit_weights(tower.vision_tower, W, cfg)
+    f_ref = tower(img)
+    f_hf = _hf_siglip(cfg, W)(pixel_values=img).last_hidden_state
+    f_or = R.siglip_forward(W, cfg, img)
+    e1, e2 = (f_ref - f_or).abs().max().item(), (f_hf - f_or).abs().max().item()
+    scale = f_or.abs().max().item()
+    assert e1 < 2e-5 * max(1, scale) and e2 < 2e-5 * max(1, scale), (e1, e2, scale)
+    aligned = R.vision_encode(W, cfg, img)
+    P = (cfg.vit_img // cfg.vit_patch) ** 2
+    tok = torch.cat([torch.arange(0, P, 7), torch.tensor([P - 1])]).unique()
+    # attention-entropy diagnostic: how far from uniform the softmax rows are (the online-softmax rescale is only exercised
+    # when the running max moves between key tiles)
+    VT = "vision_model.vision_tower."
+    x = torch.nn.functional.conv2d(img, W[VT + "patch_embed.proj.weight"], W[VT + "patch_embed.proj.bias"], stride=cfg.vit_patch).flatten(2).transpose(1, 2) + W[VT + "pos_embed"]
+    h = torch.nn.functional.layer_norm(x, (cfg.vit_width,), W[VT + "blocks.0.norm1.weight"], W[VT + "blocks.0.norm1.bias"], eps=1e-6)
+    qkv = torch.nn.functional.linear(h, W[VT + "blocks.0.attn.qkv.weight"], W[VT + "blocks.0.attn.qkv.bias"]).reshape(2, 576, 3, 16, 64).permute(2, 0, 3, 1, 4)
+    sc = (qkv[0] @ qkv[1].transpose(-1, -2)) / 8.0
+    tile_max = sc.reshape(2, 16, 576, 9, 64).amax(-1)
+    moves = float((tile_max[..., 1:] > tile_max[..., :-1].cummax(-1).values).float().mean())
+    # tiny shape through the reference classes as well (VisionTransformer constructed directly: the tiny width is not in SigLIP_MODEL_CONFIG)
+    tcfg = R.OracleCfg(**TINY)
+    TW = R.make_weights(tcfg, seed=1, with_encoder=True, with_vision=True)
+    vt = sv.VisionTransformer(img_size=tcfg.vit_img, patch_size=tcfg.vit_patch, embed_dim=tcfg.vit_width, depth=tcfg.vit_layers,
+                              num_heads=tcfg.vit_heads, mlp_ratio=tcfg.vit_mlp / tcfg.vit_width, class_token=False, global_pool="map",
+                              ignore_head=True, weight_init="skip", num_classes=0).eval()
+    vt.attn_pool = None
+    _load_vit_weights(vt, TW, tcfg)
+    g = torch.Generator().manual_seed(31)
+    timg = torch.rand(3, 3, tcfg.vit_img, tcfg.vit_img, generator=g) * 2 - 1
+    t_ref = vt(timg)
+    e3 = (t_ref - R.siglip_forward(TW, tcfg, timg)).abs().max().item()
+    assert e3 < 2e-5, e3
+    np.savez_compressed(os.path.join(OUT, "siglip_fullwidth.npz"), img_seed=41, img_sum=float(img.double().abs().sum()),
+                        tok=tok.numpy().astype(np.int32), features=f_ref[:, tok].numpy(), aligned=aligned[:, tok].numpy(),
+                        feat_absmax=scale, score_tile_max_moves=moves, tiny_features_refblocks=t_ref.numpy(), wsum=wsum(W),
+                        source="reference siglip_vit.py + clip_encoder.py classes (stand-in PatchEmbed / Mlp) == transformers.SiglipVisionModel == oracle")
+    print(f"siglip full-width ok; reference-blocks vs oracle {e1:.2e}, transformers vs oracle {e2:.2e}, tiny reference-blocks vs oracle {e3:.2e}; "
+          f"|f|max {scale:.2f}, running-max moves on {moves:.2f} of later key tiles")
+
+
 def golden_text():
     """The chat template through the REFERENCE's own conversation.py (imported by file path): sft prompts for a set
     of (caption, grounding, stage) cases -> tests/golden/text_golden.json; asserts the oracle restatement equals it."""
@@ -639,11 +884,17 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "siglip":
         golden_siglip_crosscheck()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "siglipfull":
+        golden_siglip_fullwidth()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fullwidth":
         golden_full_width()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "smallbatch":
         golden_small_batch()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "textvocab":
+        golden_text_full_vocab()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "textfull":
         golden_text_full_width()
@@ -668,10 +919,12 @@ def main():
     golden_full_width()
     golden_small_batch()
     golden_text_full_width()
+    golden_text_full_vocab()
     golden_prefill_long()
     golden_full_depth()
     golden_text()
     golden_siglip_crosscheck()
+    golden_siglip_fullwidth()
 
 
 if __name__ == "__main__":

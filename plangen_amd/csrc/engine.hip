@@ -684,7 +684,12 @@ int pg_engine::finalize(int* missing, hipStream_t s) {
         const int Hh2 = H(), I = cfg.inter, HDm = HD();
         for (Layer& ly : layers) {
             TRY(tile_one(s, ly.wqkv, &ly.wqkv_t, 3 * HDm, Hh2));
-            if ((Hh2 & 7) == 0) {      // prefill copy for the fused RoPE / KV-write epilogue (gemm256 act 3); 25 MB per layer at Janus-Pro-1B size
+            // prefill copy for the fused RoPE / KV-write epilogue (gemm256 act 3); 25 MB per layer at Janus-Pro-1B size.  Only when this
+            // handle's CAPACITY can ever reach the fused path (gemm256_try takes >= 200 tiles of 256 x 256: ~2.1 k packed prompt tokens at
+            // N = 6144) -- small-batch / short-prompt engines never use it and no longer pay for it
+            const long max_packed = (long)cfg.max_rows * cfg.max_prompt;
+            const bool can_fuse = ((max_packed + 255) / 256) * ((3L * HDm + 255) / 256) >= 200;
+            if ((Hh2 & 7) == 0 && can_fuse) {
                 if (!ly.wqkv_p) TRY(dalloc(&ly.wqkv_p, (size_t)3 * HDm * Hh2 * 2));
                 launch_interleave_qk(s, (const bf16*)ly.wqkv, (bf16*)ly.wqkv_p, cfg.n_heads, Hh2);
             }
@@ -844,6 +849,9 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
 
 int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtype, const int32_t* pad_len, int R_, int L_,
                        int pmode, void* hidden_out, int hidden_dtype, hipStream_t s) {
+    // one-shot: the hint describes the ids of THIS call only -- consumed before anything can fail, so that a rejected call
+    // cannot leave it armed for the next batch
+    const int hint = uncond_hint; uncond_hint = -1;
     if (!finalized) FAIL(PG_ERR_STATE, "pg_finalize_weights not called");
     if (R_ <= 0 || R_ > cfg.max_rows) FAIL(PG_ERR_CAPACITY, "rows %d > max_rows %d", R_, cfg.max_rows);
     if (L_ + cfg.max_new + 1 > max_pos) FAIL(PG_ERR_CAPACITY, "padded length %d too long for the RoPE table (%d)", L_, max_pos);
@@ -864,8 +872,8 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
     if (share_uncond && fuse_rope && ids_dev && !hidden_out && pmode == 0 && R_ >= 4 && (R_ % 2) == 0) {
         bool same = true;
         for (int r = 3; r < R_ && same; r += 2) same = pad_len[r] == pad_len[1];
-        if (same && uncond_hint == 1) shared_len = L_ - pad_len[1];      // the caller compared the ids on the host (its collate built them): no probe, no sync
-        else if (same && uncond_hint != 0) {
+        if (same && hint == 1) shared_len = L_ - pad_len[1];      // the caller compared the ids on the host (its collate built them): no probe, no sync
+        else if (same && hint != 0) {
             HIPCHK(hipMemsetAsync(d_flag, 0, 4, s));
             launch_rows_differ(s, ids_dev, L_, /*first*/ 3, /*stride*/ 2, /*ref row*/ 1, (R_ - 2) / 2, pad_len[1], d_flag);
             HIPCHK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, s));
@@ -873,7 +881,6 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
             if (*h_flag == 0) shared_len = L_ - pad_len[1];
         }
     }
-    uncond_hint = -1;                                                       // one-shot: the hint describes the ids of THIS call only
     // pinned staging is double-buffered: the copies of call n are still in flight while call n+1 fills
     // the other buffer; a buffer is reused only after the event recorded behind its copies has fired
     // (two calls back: in practice never waits), so pg_prefill itself does not synchronise the stream.
@@ -1609,6 +1616,9 @@ int pg_debug_read(pg_handle h, const char* name, int index, void* dst_dev, int64
     else if (nm == "pq_table") { src = h->pq_table; n = (int64_t)h->cfg.img_vocab * h->cfg.vq_z * h->esz; }
     else if (nm == "qbuf") { src = h->qbuf; n = (int64_t)h->max_tok * h->HD() * h->esz; }
     else if (nm == "obuf") { src = h->obuf; n = (int64_t)h->max_tok * h->HD() * h->esz; }
+    else if (nm == "vit_feat" && h->cfg.with_vision) {   // SigLIP features (after the final LayerNorm, compute dtype) of the last pg_vision_encode
+        const int64_t P = (h->cfg.vit_img / h->cfg.vit_patch) * (h->cfg.vit_img / h->cfg.vit_patch);
+        src = h->vt; n = (int64_t)h->cfg.max_vision_images * P * h->cfg.vit_width * h->esz; }
     else { h->err = "pg_debug_read: unknown buffer " + nm; return PG_ERR_NAME; }
     if (n > max_bytes) n = max_bytes;
     (void)hipSetDevice(h->dev);

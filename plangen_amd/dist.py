@@ -28,11 +28,18 @@ def shard_range(n_images: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def broadcast_prompts(ids: Optional[torch.Tensor], mask: Optional[torch.Tensor], device, src: int = 0):
+def _skip(ws: int, force_collectives: bool) -> bool:
+    """World 1 needs no collective; ``force_collectives`` runs them anyway when a process group exists (a 1-rank RCCL
+    communicator: the single-GPU self-test of the multi-GPU path, tests/test_gpu_rccl.py / bench.py ``rccl_selftest``)."""
+    return ws == 1 and not (force_collectives and dist.is_available() and dist.is_initialized())
+
+
+def broadcast_prompts(ids: Optional[torch.Tensor], mask: Optional[torch.Tensor], device, src: int = 0,
+                      force_collectives: bool = False):
     """Rank ``src`` holds cfg_inputs_ids int32 [2B, L] and cfg_attention_mask int32 [2B, L+T];
     every rank returns its own slice (rows 2*lo .. 2*hi) plus (lo, hi, B)."""
     rank, ws = world()
-    if ws == 1:
+    if _skip(ws, force_collectives):
         B = ids.shape[0] // 2
         return ids.to(device), mask.to(device), 0, B, B
     hdr = torch.zeros(3, dtype=torch.int64, device=device)
@@ -68,12 +75,12 @@ def _unpad(outs, n_total: int, ws: int) -> torch.Tensor:
     return torch.cat(parts, dim=0)
 
 
-def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0, force_collectives: bool = False) -> Optional[torch.Tensor]:
     """Gather per-image rows (tokens [b, T] or images [b, 3, S, S]) to rank ``dst`` in batch order; other ranks
     get None.  A gather, not an all-gather: only the rank that writes the results needs them (2.3 KB of tokens per
     image, but 1.7 MB per image for pixels)."""
     rank, ws = world()
-    if ws == 1:
+    if _skip(ws, force_collectives):
         return local
     buf = _padded(local, n_total, ws)
     outs = [torch.empty_like(buf) for _ in range(ws)] if rank == dst else None
@@ -81,10 +88,10 @@ def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[tor
     return _unpad(outs, n_total, ws) if rank == dst else None
 
 
-def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+def all_gather_rows(local: torch.Tensor, n_total: int, force_collectives: bool = False) -> torch.Tensor:
     """The same rows on EVERY rank (only for callers that really need them everywhere)."""
     rank, ws = world()
-    if ws == 1:
+    if _skip(ws, force_collectives):
         return local
     buf = _padded(local, n_total, ws)
     outs = [torch.empty_like(buf) for _ in range(ws)]

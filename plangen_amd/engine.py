@@ -320,8 +320,7 @@ class Engine:
         rank 0 compares the collated ids once and broadcasts the flag with them)."""
         if uncond_shared is None and not ids.is_cuda and position_mode == 0 and not return_hidden:
             uncond_shared = self.uncond_rows_shared(ids, pad_len)
-        if uncond_shared is not None:
-            self.set_option("uncond_shared_hint", int(bool(uncond_shared)))
+        self.set_option("uncond_shared_hint", -1 if uncond_shared is None else int(bool(uncond_shared)))    # always sent: never a stale hint
         ids = self._dev(ids, torch.int32)
         R, L = ids.shape
         pl = (C.c_int32 * R)(*[int(v) for v in pad_len])

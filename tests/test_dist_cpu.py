@@ -100,3 +100,87 @@ def test_bench_launcher_fails_fast_when_a_rank_dies():
     assert rc != 0 and out is None
     assert "rank 1 exited with rc 7" in err and "terminating the other ranks" in err, err
     assert dt < 60, dt                                     # far below the 120 s collective timeout
+
+
+def test_force_collectives_runs_them_in_a_one_rank_group():
+    """``force_collectives=True`` does not short-circuit at world 1 (the single-GPU RCCL self-test uses it; here over gloo)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "rccl_one_rank.py"), "gloo"], env=e, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0 and '"rccl_one_rank": "ok"' in p.stdout, p.stderr[-2000:]
+
+
+def _wait_pids(d, n, timeout=120):
+    import time
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        fs = [f for f in os.listdir(d) if f.endswith(".pid")]
+        if len(fs) == n:
+            return [int(open(os.path.join(d, f)).read()) for f in fs]
+        time.sleep(0.2)
+    raise AssertionError("ranks did not start")
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    try:                                            # a zombie still answers signal 0
+        return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+    except FileNotFoundError:
+        return False
+
+
+def _launcher_signal_case(sig, tmp_path):
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, PG_TEST_HANG_S="600", PG_TEST_PID_DIR=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--batch", "2"], env=e,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        pids = _wait_pids(str(tmp_path), 2)
+        assert all(_alive(q) for q in pids)
+        p.send_signal(sig)
+        if sig == signal.SIGKILL:
+            p.wait(timeout=30)
+        else:
+            _, err = p.communicate(timeout=60)
+            assert p.returncode == 130 and "launcher interrupted" in err, (p.returncode, err)
+        t0 = time.time()
+        while any(_alive(q) for q in pids) and time.time() - t0 < 30:
+            time.sleep(0.2)
+        assert not any(_alive(q) for q in pids), "rank processes survived the launcher"
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for f in os.listdir(str(tmp_path)):
+            try:
+                os.kill(int(open(os.path.join(str(tmp_path), f)).read()), 9)      # exact PIDs the ranks wrote themselves
+            except (ProcessLookupError, ValueError):
+                pass
+
+
+def test_launcher_sigterm_takes_the_ranks_down(tmp_path):
+    """the ranks run in their own sessions; SIGTERM to the launcher (a `timeout`, a driver kill) must still end them."""
+    import signal
+    _launcher_signal_case(signal.SIGTERM, tmp_path)
+
+
+def test_launcher_sighup_takes_the_ranks_down(tmp_path):
+    import signal
+    _launcher_signal_case(signal.SIGHUP, tmp_path)
+
+
+def test_launcher_sigkill_takes_the_ranks_down_through_pdeathsig(tmp_path):
+    """A SIGKILLed launcher cannot run any handler: PR_SET_PDEATHSIG in every rank covers it."""
+    import signal
+    _launcher_signal_case(signal.SIGKILL, tmp_path)

@@ -1,0 +1,120 @@
+"""GPU: the SigLIP-L tower at its PRODUCTION SHAPE against tests/golden/siglip_fullwidth.npz
+(oracle/make_golden.py::golden_siglip_fullwidth: the reference's own siglip_vit.py / clip_encoder.py classes with labelled
+stand-ins for timm's PatchEmbed / Mlp == transformers.SiglipVisionModel == oracle.siglip_forward, all three equal at
+generation time).
+
+Width 1024, 16 heads x 64, MLP 4096, patch 16, 384^2 -> 576 tokens, 2 layers, 2 images; DEFAULT engine options.  In bf16 this
+runs what config 5 (mmu) runs and the tiny fixtures (64 tokens, width 128) never reach:
+  * attn_vit_flash_kernel over 9 key tiles x 9 query tiles per (image, head): the online-softmax rescale between key tiles
+    (the fixture's running maximum moves on 23 % of the later key tiles, `score_tile_max_moves`),
+  * layernorm_wave_kernel<T,4> (dispatched only at C == 1024),
+  * the K = 1024 / 4096 GEMM shapes with bias + GELU epilogues and the in-place fp32 residual (qkv, V^T with swapped operands,
+    proj, fc1, fc2, aligner 1024 -> 2048 -> 2048).
+Tolerances: PG_F32 2e-3 of the feature scale (|f| max 4.9; fp32 summation order over K up to 4096);
+PG_BF16: measured on MI355X (printed, written to gpurun_out/siglip_fullwidth_bf16_stats.json), asserted bound stated below.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from fullwidth_cfg import VISW, siglip_fullwidth_images
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+_S = {}
+
+
+def _setup():
+    if "W" not in _S:
+        from plangen_amd.config import PlanGenConfig
+        g = load_golden("siglip_fullwidth.npz")
+        ocfg = R.OracleCfg(**VISW)
+        W = R.make_weights(ocfg, seed=7, with_vision=True)
+        ws = float(sum(v.double().abs().sum() for v in W.values()))
+        assert abs(ws - float(g["wsum"])) < 1e-6 * ws, "seeded weights drifted from the ones the fixture was generated with"
+        img = siglip_fullwidth_images(seed=int(g["img_seed"]))
+        assert abs(float(img.double().abs().sum()) - float(g["img_sum"])) < 1e-6 * float(g["img_sum"]), "seeded images drifted"
+        _S.update(W=W, g=g, cfg=PlanGenConfig(**VISW), ocfg=ocfg, img=img)
+    return _S
+
+
+def _engine(dtype, **opts):
+    from plangen_amd.engine import Engine
+    s = _setup()
+    key = (dtype, tuple(sorted(opts.items())))
+    if key not in _S:
+        for k in [k for k in _S if isinstance(k, tuple)]:
+            _S.pop(k).close()
+        e = Engine(s["cfg"], dtype=dtype, max_rows=4, max_prompt=32, max_new=8, max_images=2, with_vision=True, max_vision_images=2)
+        e.load_state_dict(s["W"])
+        for k, v in opts.items():
+            e.set_option(k, v)
+        _S[key] = e
+    return _S[key]
+
+
+def _run(e):
+    s = _setup()
+    cfg = s["cfg"]
+    out = e.vision_encode(s["img"]).float().cpu()
+    P, C = cfg.vit_tokens, cfg.vit_width
+    feat = e.debug_read("vit_feat", 0, 2 * P * C, torch.float32 if e.dtype == "f32" else torch.bfloat16).float().cpu().reshape(2, P, C)
+    tok = torch.from_numpy(s["g"]["tok"]).long()
+    return out[:, tok], feat[:, tok]
+
+
+def test_siglip_fullwidth_f32_matches_reference_blocks():
+    g = _setup()["g"]
+    al, ft = _run(_engine("f32"))
+    ref_f, ref_a = torch.from_numpy(g["features"]), torch.from_numpy(g["aligned"])
+    ef, ea = (ft - ref_f).abs().max().item(), (al - ref_a).abs().max().item()
+    print(f"siglip full width f32: features err {ef:.2e} (|f| max {float(g['feat_absmax']):.2f}), aligned err {ea:.2e} (|a| max {ref_a.abs().max():.2f})")
+    assert ef < 2e-3 * max(1.0, ref_f.abs().max().item())
+    assert ea < 2e-3 * max(1.0, ref_a.abs().max().item())
+
+
+# bf16, two layers, LayerNorm'd features of scale ~5: measured on MI355X (round 4) max |err| see gpurun_out/siglip_fullwidth_bf16_stats.json;
+# bounds = 1.5x measured, tightened after the first GPU run (the tiny test's bound is 6e-2 of the output scale).
+FEAT_TOL_BF16 = 0.09
+ALIGNED_TOL_BF16 = 0.06
+
+
+def test_siglip_fullwidth_bf16_default_options():
+    """The production dispatch: flash attention (9 x 9 tiles), wave LayerNorm, 256x256 / 128x128 GEMMs with epilogues."""
+    g = _setup()["g"]
+    al, ft = _run(_engine("bf16"))
+    ref_f, ref_a = torch.from_numpy(g["features"]), torch.from_numpy(g["aligned"])
+    df, da = (ft - ref_f).abs(), (al - ref_a).abs()
+    stats = dict(feat_max=df.max().item(), feat_p99=df.flatten().quantile(0.99).item(), feat_scale=ref_f.abs().max().item(),
+                 aligned_max=da.max().item(), aligned_p99=da.flatten().quantile(0.99).item(), aligned_scale=ref_a.abs().max().item(),
+                 per_query_tile_max=[df[:, (torch.from_numpy(g["tok"]).long() // 64) == t].max().item() for t in range(9)])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(stats, open(os.path.join(ROOT, "gpurun_out", "siglip_fullwidth_bf16_stats.json"), "w"), indent=1)
+    print("siglip full width bf16:", stats)
+    assert stats["feat_max"] < FEAT_TOL_BF16 and stats["aligned_max"] < ALIGNED_TOL_BF16, stats
+    # no query tile stands out: a tile-indexing fault in the 9 x 9 flash loop shows as one tile far above the others
+    assert max(stats["per_query_tile_max"]) < 4 * (sorted(stats["per_query_tile_max"])[4] + 1e-3), stats
+
+
+def test_siglip_fullwidth_bf16_flash_equals_unfused_attention():
+    """attn_vit_flash_kernel vs the batched QK^T / softmax / PV GEMM path (flash_prefill=0) on the same engine weights: the two
+    round differently (P in bf16 after vs before normalisation) but must stay inside the bf16 bound of each other."""
+    a1, f1 = _run(_engine("bf16"))
+    a0, f0 = _run(_engine("bf16", flash_prefill=0))
+    d = (f1 - f0).abs().max().item()
+    print("flash vs unfused features:", d)
+    assert d < FEAT_TOL_BF16
+
+
+def test_siglip_fullwidth_batch_rows_independent():
+    """Image 1 alone == image 1 in the batch of two, bit for bit (no cross-image term anywhere)."""
+    e = _engine("bf16")
+    s = _setup()
+    both = e.vision_encode(s["img"]).cpu()
+    one = e.vision_encode(s["img"][1:2]).cpu()
+    assert torch.equal(both[1], one[0])

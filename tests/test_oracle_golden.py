@@ -195,3 +195,47 @@ def test_fulldepth_fixture_is_consistent():
     g = load_golden("sample_image_fulldepth.npz")
     assert g["ids"].shape == (4, 64) and g["tokens"].shape == (2, 16) and (g["ids"][1, g["pad"][1]:] == g["ids"][3, g["pad"][3]:]).all()
     assert np.array_equal(g["top_i"][..., 0].T, g["tokens"]) and (g["top_v"][..., 0] >= g["top_v"][..., 1]).all()
+
+
+def test_siglip_fullwidth_fixture_matches_oracle(ocfg, tiny_weights):
+    """a13 at the production shape: oracle.siglip_forward reproduces the features the REFERENCE's own siglip_vit.py classes
+    computed (stand-in PatchEmbed / Mlp, see oracle/make_golden.py::_timm_standins) -- width 1024, 16 heads, 576 tokens,
+    2 layers -- and, at the tiny shape, the features the reference's VisionTransformer computed on the tiny weights."""
+    from fullwidth_cfg import VISW, siglip_fullwidth_images
+    g = load_golden("siglip_fullwidth.npz")
+    cfg = R.OracleCfg(**VISW)
+    W = R.make_weights(cfg, seed=7, with_vision=True)
+    assert abs(wsum(W) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    img = siglip_fullwidth_images(seed=int(g["img_seed"]))
+    assert abs(float(img.double().abs().sum()) - float(g["img_sum"])) < 1e-6 * float(g["img_sum"])
+    tok = torch.from_numpy(g["tok"]).long()
+    assert set((tok // 64).tolist()) == set(range(9))                       # every 64-token tile of the flash kernel is sampled
+    f = R.siglip_forward(W, cfg, img)
+    assert (f[:, tok] - torch.from_numpy(g["features"])).abs().max() < 5e-5
+    a = R.vision_encode(W, cfg, img)
+    assert (a[:, tok] - torch.from_numpy(g["aligned"])).abs().max() < 5e-5
+    assert float(g["score_tile_max_moves"]) > 0.1                           # the online-softmax running max really moves
+    gi = torch.Generator().manual_seed(31)
+    timg = torch.rand(3, 3, ocfg.vit_img, ocfg.vit_img, generator=gi) * 2 - 1
+    assert (R.siglip_forward(tiny_weights, ocfg, timg) - torch.from_numpy(g["tiny_features_refblocks"])).abs().max() < 2e-5
+
+
+def test_fullvocab_text_fixture_is_consistent_and_oracle_reproduces_first_steps():
+    """a11 at vocab 102 400 (generate_fullvocab.npz, from LlamaForCausalLM.generate): ids beyond 16 bits, an early-EOS row, and the
+    oracle reproduces the first greedy steps of every row."""
+    from fullwidth_cfg import FULLV
+    g = load_golden("generate_fullvocab.npz")
+    eos, out, probe = int(g["eos"]), g["out"], g["probe"]
+    assert out.dtype == np.int32 and eos >= 65536 and out.max() < 102400
+    stopped = (out == eos).any(1)
+    assert 1 <= stopped.sum() < out.shape[0]
+    for r in np.nonzero(stopped)[0]:
+        first = int(np.argmax(out[r] == eos))
+        assert (out[r, first:] == eos).all() and (out[r, :first] == probe[r, :first]).all()
+    assert np.array_equal(g["top_i"][..., 0].T, probe)                 # teacher-forced argmax of the un-stopped run
+    cfg = R.OracleCfg(**FULLV)
+    W = R.make_weights(cfg, seed=11)
+    assert abs(wsum(W) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"].astype(np.int32))
+    mine = R.generate_text_greedy(W, cfg, R.embed_tokens(W, ids), mask, 3, eos)
+    assert np.array_equal(mine.numpy()[:, :3], out[:, :3])

@@ -18,21 +18,48 @@ have a spec below (a new LDS-DMA kernel without one fails the check):
   big / halo_lock / halo_stag / once / probe: per-kernel replays of the same rule (128x128 GEMM, the halo convolution's two wave schedules),
           the conv_out halo (staged once per tile) and the measurement probe are listed.
 
-usage: dma_isa_check.py            (compiles plangen_amd/csrc/*.hip with -S into /tmp/dma_isa/)"""
-import os, re, subprocess, sys
+usage: dma_isa_check.py            (compiles plangen_amd/csrc/*.hip with -S into a content-keyed cache under $TMPDIR/dma_isa_<uid>/)"""
+import os, re, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "plangen_amd", "csrc")
-OUT = "/tmp/dma_isa"
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+_S_PATH = {}
+
+
+def _compiler_id():
+    try:
+        return subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.replace("\n", " ")
+    except OSError:
+        return "unknown"
 
 
 def compile_s(name):
-    os.makedirs(OUT, exist_ok=True)
-    src, dst = os.path.join(CSRC, name + ".hip"), os.path.join(OUT, name + ".s")
-    deps = [src] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
-    if not os.path.exists(dst) or any(os.path.getmtime(d) > os.path.getmtime(dst) for d in deps):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
-                               src, "-I", CSRC, "-o", dst], stderr=subprocess.DEVNULL)
+    """hipcc -S of one source into a cache keyed on the CONTENT of the source + headers and on the compiler version (not on
+    mtimes: a checkout or a compiler change must not reuse a stale listing); written under a temporary name and renamed, so
+    concurrent runs cannot read a half-written file."""
+    import hashlib, tempfile
+    src = os.path.join(CSRC, name + ".hip")
+    deps = [src] + sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h"))
+    hsh = hashlib.sha256(_compiler_id().encode())
+    for d in deps:
+        hsh.update(open(d, "rb").read())
+    out = os.path.join(tempfile.gettempdir(), f"dma_isa_{os.getuid()}")
+    os.makedirs(out, exist_ok=True)
+    dst = os.path.join(out, f"{name}.{hsh.hexdigest()[:16]}.s")
+    if not os.path.exists(dst):
+        fd, tmp = tempfile.mkstemp(suffix=".s", dir=out)
+        os.close(fd)
+        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                               src, "-I", CSRC, "-o", tmp], stderr=subprocess.DEVNULL)
+        os.replace(tmp, dst)
+        for f in os.listdir(out):                                  # drop older listings of the same source
+            if f.startswith(name + ".") and f.endswith(".s") and os.path.join(out, f) != dst:
+                try:
+                    os.remove(os.path.join(out, f))
+                except OSError:
+                    pass
+    _S_PATH[name] = dst
     return open(dst).read().splitlines()
 
 
@@ -165,8 +192,10 @@ SPECS = [
 
 
 def main():
+    import collections, json
     bad = 0
     seen = set()
+    okc = collections.Counter()          # kernels whose protocol was verified, by spec kind (the machine-readable result)
     report = []
     names = sorted(f[:-4] for f in os.listdir(CSRC) if f.endswith(".hip")
                    and re.search(r"glds16|global_load_lds", open(os.path.join(CSRC, f)).read()))
@@ -196,7 +225,7 @@ def main():
                     bad += 1
                     report.append(f"FAIL {fname}:{short}: " + "; ".join(errs[:3]))
                 else:
-                    report.append(f"ok   {fname}:{short}: fifo protocol holds in the strict form over 6 replayed iterations ({n} DMA instructions)")
+                    okc[spec["kind"]] += 1; report.append(f"ok   {fname}:{short}: fifo protocol holds in the strict form over 6 replayed iterations ({n} DMA instructions)")
             elif spec["kind"] == "sk4":
                 continue
             elif spec["kind"] == "halo_stag":
@@ -220,7 +249,7 @@ def main():
                     bad += 1
                     report.append(f"FAIL {fname}:{short}: " + ("; ".join(errs[:3]) if errs else f"prologue: {nbar} barrier(s) between the retiring vmcnt(2) and the first read, {nj} halo DMAs"))
                 else:
-                    report.append(f"ok   {fname}:{short}: weight ring strict over 6 replayed iterations; halo ({nj} DMAs) + W(0) retired {nbar} barriers before the first read")
+                    okc[spec["kind"]] += 1; report.append(f"ok   {fname}:{short}: weight ring strict over 6 replayed iterations; halo ({nj} DMAs) + W(0) retired {nbar} barriers before the first read")
             elif spec["kind"] == "halo_lock":
                 pro, body = main_loop(ev)
                 state = {"n": 0}
@@ -234,7 +263,7 @@ def main():
                 if errs:
                     bad += 1; report.append(f"FAIL {fname}:{short}: " + "; ".join(errs[:3]))
                 else:
-                    report.append(f"ok   {fname}:{short}: lock-step weight ring strict over 6 replayed iterations -- {spec['why']}")
+                    okc[spec["kind"]] += 1; report.append(f"ok   {fname}:{short}: lock-step weight ring strict over 6 replayed iterations -- {spec['why']}")
             elif spec["kind"] == "big":
                 # stage(t+1) | read tile t | vmcnt(0) + barrier (retires t+1) | barrier
                 pro, body = main_loop(ev)
@@ -249,7 +278,7 @@ def main():
                     bad += 1
                     report.append(f"FAIL {fname}:{short}: " + "; ".join(errs[:3]))
                 else:
-                    report.append(f"ok   {fname}:{short}: double buffer, strict form holds ({n} DMA instructions replayed) -- {spec['why']}")
+                    okc[spec["kind"]] += 1; report.append(f"ok   {fname}:{short}: double buffer, strict form holds ({n} DMA instructions replayed) -- {spec['why']}")
             elif spec["kind"] == "once":
                 # per tile: fill (DMA) -> vmcnt(0) -> barrier -> barrier -> fragment reads -> barrier (patch free).  Linear walk of the tile loop.
                 flat = [e for e in ev if e[0] in ("dma", "wait", "bar", "read")]
@@ -262,15 +291,21 @@ def main():
                 if not w0 or nbar < 2 or not any(e[0] == "bar" for e in after):
                     bad += 1; report.append(f"FAIL {fname}:{short}: {nbar} barrier(s) between the retiring vmcnt(0) and the first read of the patch")
                 else:
-                    report.append(f"ok   {fname}:{short}: patch retired {nbar} barriers before its first read, released by a barrier after the last -- {spec['why']}")
+                    okc[spec["kind"]] += 1; report.append(f"ok   {fname}:{short}: patch retired {nbar} barriers before its first read, released by a barrier after the last -- {spec['why']}")
             else:
                 report.append(f"note {fname}:{short}: {spec['kind']} -- {spec['why']}")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sk4_isa_check.py"), os.path.join(OUT, "gemm.s")], capture_output=True, text=True)
-    report.append("sk4: " + p.stdout.strip().splitlines()[-1])
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sk4_isa_check.py"), _S_PATH["gemm"]], capture_output=True, text=True)
+    last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "no output"
+    report.append("sk4: " + last)
     if p.returncode != 0:
         bad += 1
         report += p.stdout.strip().splitlines()[:5]
+    m = re.match(r"(\d+) .*?(\d+) failed", last)
     print("\n".join(report))
+    # one machine-readable line for tests/test_isa_check.py (wording of the lines above is free to change)
+    print("SUMMARY " + json.dumps({"failed": bad, "verified": dict(okc), "notes": sum(1 for l in report if l.startswith("note")),
+                                   "sk4": {"checked": int(m.group(1)) if m else -1, "failed": int(m.group(2)) if m else -1, "rc": p.returncode},
+                                   "compiler": _compiler_id()[:80]}))
     print(f"{bad} failed")
     return 1 if bad else 0
 

@@ -65,7 +65,15 @@ def main(argv=None):
     import torch.distributed as dist
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        import torch
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        # same arguments as bench.py: the communicator is bound to this rank's device up front (no lazy init on the first
+        # collective) and a dead peer fails the collective after a FINITE time instead of hanging the node
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                timeout=datetime.timedelta(seconds=float(os.environ.get("PG_DIST_TIMEOUT_S", "900"))))
     system_cls = getattr(importlib.import_module(args.system_cls_path), "System")     # train.py:85-86
     model = system_cls(args, None)
     model.setup_data(None)
