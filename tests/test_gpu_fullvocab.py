@@ -74,7 +74,7 @@ def test_fullvocab_text_greedy_f32_matches_hf_generate():
 
 
 def test_fullvocab_text_greedy_bf16_vs_oracle_logits():
-    TEXT_TOL = 0.10                      # same bound as the vocab-4096 fixture (measured there 0.046); measured value printed
+    TEXT_TOL = 0.05                      # measured on MI355X (round 4): worst gap 0.0254, argmax agreement 97.2 %, 52 of 144 ids >= 65 536
     s = _setup()
     g = s["g"]
     out = _x2t("bf16", s["cfg"].eos_id, min_new_tokens=N_NEW)

@@ -78,10 +78,11 @@ def test_siglip_fullwidth_f32_matches_reference_blocks():
     assert ea < 2e-3 * max(1.0, ref_a.abs().max().item())
 
 
-# bf16, two layers, LayerNorm'd features of scale ~5: measured on MI355X (round 4) max |err| see gpurun_out/siglip_fullwidth_bf16_stats.json;
-# bounds = 1.5x measured, tightened after the first GPU run (the tiny test's bound is 6e-2 of the output scale).
-FEAT_TOL_BF16 = 0.09
-ALIGNED_TOL_BF16 = 0.06
+# bf16, two layers, LayerNorm'd features of scale ~5.  Measured on MI355X (round 4, gpurun_out/siglip_fullwidth_bf16_stats.json):
+# features max |err| 0.0515 (p99 0.024), aligned 0.0565 (p99 0.026), per-query-tile maxima 0.037..0.052 (flat), flash vs unfused
+# attention 0.023.  Bounds = 1.5x measured.
+FEAT_TOL_BF16 = 0.08
+ALIGNED_TOL_BF16 = 0.085
 
 
 def test_siglip_fullwidth_bf16_default_options():
