@@ -413,3 +413,31 @@ extern "C" int pg_bench_tr16_probe(const int* addr_host, unsigned short* out_hos
     hipFree(a); hipFree(o);
     return rc;
 }
+
+
+// Background memory load for hazard screens (tools/sk4_load_stress.py): the run-ahead weight stream kernel free-running over a private
+// ``mb`` MB buffer on its own stream while the caller launches the kernel under test.  mode 0: LDS-DMA sink, 1: LDS-DMA nt, 2: register loads.
+static hipStream_t g_bg_stream = nullptr; static char* g_bg_buf = nullptr; static PfLayer* g_bg_plan = nullptr; static uint32_t* g_bg_words = nullptr;
+extern "C" int pg_bench_background(int mb, int passes, int blocks, int depth, int mode) {
+    if (!g_bg_stream) {
+        if (hipStreamCreateWithFlags(&g_bg_stream, hipStreamNonBlocking) != hipSuccess) return -2;
+        if (hipMalloc((void**)&g_bg_plan, sizeof(PfLayer)) != hipSuccess || hipMalloc((void**)&g_bg_words, 64) != hipSuccess) return -2;
+        hipMemset(g_bg_words, 0, 64);
+    }
+    static int cur_mb = 0;
+    if (mb != cur_mb) {
+        if (g_bg_buf) { hipStreamSynchronize(g_bg_stream); hipFree(g_bg_buf); g_bg_buf = nullptr; }
+        if (hipMalloc((void**)&g_bg_buf, (size_t)mb << 20) != hipSuccess) return -2;
+        hipMemset(g_bg_buf, 1, (size_t)mb << 20);
+        cur_mb = mb;
+    }
+    PfLayer pl{}; pl.m[0].base = g_bg_buf; pl.m[0].kib = (uint32_t)mb * 1024u; pl.m[0].regions = 64;
+    hipMemcpy(g_bg_plan, &pl, sizeof(pl), hipMemcpyHostToDevice);
+    launch_weight_prefetch(g_bg_stream, g_bg_plan, 1, g_bg_words, passes, 0, 0, 0, blocks, mode == 2 ? -1 : depth, mode == 1, g_bg_words + 4);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int pg_bench_background_done() {        // 1 when the background kernel has finished (non-blocking)
+    if (!g_bg_stream) return 1;
+    return hipStreamQuery(g_bg_stream) == hipSuccess ? 1 : 0;
+}
+extern "C" int pg_bench_background_join() { return g_bg_stream && hipStreamSynchronize(g_bg_stream) != hipSuccess ? -2 : 0; }

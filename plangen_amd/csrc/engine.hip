@@ -174,6 +174,10 @@ struct pg_engine {
     int h_len_off = 0; int lanes_opt = -1;   // -1 auto, 1, 2
     float* part2 = nullptr; hipStream_t istream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int32_t* d_ndec2 = nullptr;
+    // run-ahead weight stream through the Infinity Cache (weight_prefetch_kernel on its own stream, paced by d_prog)
+    int mall_prefetch = 0, pf_blocks = 256, pf_depth = 16, pf_nt = 0, pf_first = 2;
+    uint32_t* d_prog = nullptr; PfLayer* d_pfplan = nullptr; uint32_t* d_pfstats = nullptr; bool pf_plan_ok = false;
+    hipStream_t pf_stream = nullptr; hipEvent_t ev_pf0 = nullptr, ev_pf1 = nullptr; bool pf_live = false;
     int32_t* d_row_order = nullptr; bool lpt_order = true; bool order_valid = false; int order_rows = 0;
     SeqState seq() const { return SeqState{d_len, d_pos_off, d_ndec, d_tok_row, d_tok_j, shared_len, shared_row, (lpt_order && order_valid && kv_row_off == 0 && R == order_rows) ? d_row_order : nullptr}; }
 
@@ -550,6 +554,12 @@ int pg_engine::create() {
     }
     HIPCHK(hipStreamCreateWithFlags(&istream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&istream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ev_pf0, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_pf1, hipEventDisableTiming));
+    TRY(dalloc(&d_prog, 64));
+    TRY(dalloc(&d_pfstats, 64));
+    TRY(dalloc(&d_pfplan, sizeof(PfLayer) * (size_t)(cfg.n_layers > 0 ? cfg.n_layers : 1)));
     HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
@@ -579,6 +589,9 @@ void pg_engine::destroy() {
     for (hipEvent_t e : tc_ev) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {ev_in, ev_out, ev_t0, ev_t1, ev_p0, ev_p1, ev_v0, ev_v1, ev_fork, ev_join};
     if (istream2) (void)hipStreamDestroy(istream2);
+    if (pf_stream) { (void)hipStreamSynchronize(pf_stream); (void)hipStreamDestroy(pf_stream); }
+    if (ev_pf0) (void)hipEventDestroy(ev_pf0);
+    if (ev_pf1) (void)hipEventDestroy(ev_pf1);
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     if (istream) (void)hipStreamDestroy(istream);
 }
@@ -700,6 +713,21 @@ int pg_engine::finalize(int* missing, hipStream_t s) {
         TRY(tile_one(s, gh_w1, &gh_w1_t, cfg.gen_head_dim, Hh2));
         TRY(tile_one(s, gh_w2, &gh_w2_t, cfg.img_vocab, cfg.gen_head_dim));
         if (lm_head) TRY(tile_one(s, lm_head, &lm_head_t, cfg.vocab, Hh2));
+        {   // what the run-ahead weight stream reads behind layer l's o_proj: gate|up(l), down(l), then qkv(l+1) -- or, behind the last
+            // layer, the two gen_head matrices.  regions = consumer blocks of 128 columns (their K streams are contiguous in the tiled copy)
+            std::vector<PfLayer> plan((size_t)cfg.n_layers);
+            auto mat = [&](const void* p, long n, long k) { PfMat m{}; m.base = p; m.kib = (uint32_t)(n * k * 2 / 1024); m.regions = (uint32_t)((n + 127) / 128); return m; };
+            for (int li = 0; li < cfg.n_layers; ++li) {
+                PfLayer& pl = plan[(size_t)li]; pl = PfLayer{};
+                pl.m[0] = mat(layers[li].wgu_t, 2L * I, Hh2);
+                pl.m[1] = mat(layers[li].wd_t, Hh2, I);
+                if (li + 1 < cfg.n_layers) pl.m[2] = mat(layers[li + 1].wqkv_t, 3L * HDm, Hh2);
+                else { pl.m[2] = mat(gh_w1_t, cfg.gen_head_dim, Hh2); pl.m[3] = mat(gh_w2_t, cfg.img_vocab, cfg.gen_head_dim); }
+            }
+            HIPCHK(hipMemcpyAsync(d_pfplan, plan.data(), sizeof(PfLayer) * plan.size(), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            pf_plan_ok = true;
+        }
         HIPCHK(hipStreamSynchronize(s));
     }
     HIPCHK(hipGetLastError());
@@ -763,7 +791,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         const Layer& ly = layers[li];
         tic(s); toc(s, TC_EMPTY, 0.0);          // an event pair around nothing: what the instrumentation itself adds to every timed launch
         tic(s);
-        launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);
+        launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps, nullptr, sk ? d_prog : nullptr);
         toc(s, TC_NORM, norm_bytes(S_pend));
         tic(s);
         bool qkv_fused = false;
@@ -813,7 +841,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         else gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk, ly.wo_t);
         toc(s, TC_O, (double)Hh * HDm * wb);
         tic(s);
-        launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);
+        launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps, nullptr, sk ? d_prog : nullptr);
         toc(s, TC_NORM, norm_bytes(S_last));
         bool fused = false;
         tic(s);
@@ -842,7 +870,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         S_pend = S_last; slab_pend = slab_last;
     }
     tic(s);
-    launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps, advance);
+    launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps, advance, sk ? d_prog : nullptr);
     toc(s, TC_NORM, norm_bytes(S_pend));
     tc_on = false;
 }
@@ -1041,6 +1069,16 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
         if (force_mask) HIPCHK(hipMemcpyAsync(d_force_mask, force_mask, (size_t)B * T, hipMemcpyDeviceToDevice, ws));
     }
     if (free_lanes) { HIPCHK(hipEventRecord(ev_fork, ws)); HIPCHK(hipStreamWaitEvent(istream2, ev_fork, 0)); }
+    // run-ahead weight stream (option mall_prefetch, stream launches only): ticket zeroed on the work stream, ONE cross-stream edge
+    // per call hands the side stream its start, the prefetcher then paces itself on the tickets of this call's T - 1 forwards
+    const bool pf = mall_prefetch > 0 && pf_plan_ok && bf && !graph && nl == 1 && !time_attn && T > 2;
+    if (pf) {
+        HIPCHK(hipMemsetAsync(d_prog, 0, 4, ws));
+        HIPCHK(hipEventRecord(ev_pf0, ws));
+        HIPCHK(hipStreamWaitEvent(pf_stream, ev_pf0, 0));
+        launch_weight_prefetch(pf_stream, d_pfplan, cfg.n_layers, d_prog, T - 1, 2 * cfg.n_layers + 1, pf_first, 2, pf_blocks, pf_depth, pf_nt, d_pfstats);
+        HIPCHK(hipEventRecord(ev_pf1, pf_stream));
+    }
     TRY(iteration(T > 1));
     if (T > 1) n_dec_host++;
     int i = 1;
@@ -1067,6 +1105,7 @@ int pg_engine::decode_image(int T, float cfgw, float temp, uint64_t seed, const 
     }
     if (T > 1) TRY(iteration(false));
     if (free_lanes) { HIPCHK(hipEventRecord(ev_join, istream2)); HIPCHK(hipStreamWaitEvent(ws, ev_join, 0)); }
+    if (pf) HIPCHK(hipStreamWaitEvent(ws, ev_pf1, 0));       // the prefetcher has left before the next call re-zeroes its ticket (it exits with the last forward's tickets)
     HIPCHK(hipMemcpyAsync(out_tok, d_out_tok, (size_t)B * T * 4, hipMemcpyDeviceToDevice, ws));
     HIPCHK(hipEventRecord(ev_t1, ws));
     if (ws != s) {
@@ -1558,6 +1597,11 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "uncond_shared_hint")) { h->uncond_hint = value < 0 ? -1 : (value != 0); return PG_OK; }
     if (!strcmp(key, "flash_prefill")) { h->flash_prefill = value != 0; return PG_OK; }
     if (!strcmp(key, "lanes")) { h->lanes_opt = (int)value; return PG_OK; }
+    if (!strcmp(key, "mall_prefetch")) { h->mall_prefetch = (int)value; return PG_OK; }
+    if (!strcmp(key, "pf_blocks")) { h->pf_blocks = value > 0 ? (int)value : 256; return PG_OK; }
+    if (!strcmp(key, "pf_depth")) { h->pf_depth = (int)value; return PG_OK; }
+    if (!strcmp(key, "pf_nt")) { h->pf_nt = value != 0; return PG_OK; }
+    if (!strcmp(key, "pf_first")) { h->pf_first = (int)value; return PG_OK; }
     if (!strcmp(key, "gemm256")) { h->tune.gemm256 = (int)value; return PG_OK; }
     if (!strcmp(key, "conv_halo")) { h->tune.conv_halo = (int)value; return PG_OK; }
     if (!strcmp(key, "wt_store")) { h->tune.wt_store = (int)value; h->tune_epoch++; return PG_OK; }
@@ -1616,6 +1660,7 @@ int pg_debug_read(pg_handle h, const char* name, int index, void* dst_dev, int64
     else if (nm == "pq_table") { src = h->pq_table; n = (int64_t)h->cfg.img_vocab * h->cfg.vq_z * h->esz; }
     else if (nm == "qbuf") { src = h->qbuf; n = (int64_t)h->max_tok * h->HD() * h->esz; }
     else if (nm == "obuf") { src = h->obuf; n = (int64_t)h->max_tok * h->HD() * h->esz; }
+    else if (nm == "pf_stats") { src = h->d_pfstats; n = 16; }
     else if (nm == "vit_feat" && h->cfg.with_vision) {   // SigLIP features (after the final LayerNorm, compute dtype) of the last pg_vision_encode
         const int64_t P = (h->cfg.vit_img / h->cfg.vit_patch) * (h->cfg.vit_img / h->cfg.vit_patch);
         src = h->vt; n = (int64_t)h->cfg.max_vision_images * P * h->cfg.vit_width * h->esz; }
@@ -1624,6 +1669,20 @@ int pg_debug_read(pg_handle h, const char* name, int index, void* dst_dev, int64
     (void)hipSetDevice(h->dev);
     if (hipMemcpyAsync(dst_dev, src, (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)s) != hipSuccess) { h->err = "pg_debug_read: copy failed"; return PG_ERR_HIP; }
     return PG_OK;
+}
+
+// Measurement / stress only (tools/sk4_load_stress.py): the run-ahead weight stream kernel FREE-RUNNING over the engine's decode weights on
+// the handle's side stream (``passes`` sweeps of every layer's list; depth < 0 = register-destination loads instead of LDS-DMA).
+int pg_bench_background_stream(pg_handle h, int passes, int blocks, int depth, int nt) {
+    if (!h || !h->pf_plan_ok) return PG_ERR_STATE;
+    (void)hipSetDevice(h->dev);
+    launch_weight_prefetch(h->pf_stream, h->d_pfplan, h->cfg.n_layers, h->d_prog, passes, 0, 0, 0, blocks > 0 ? blocks : 256, depth, nt, h->d_pfstats);
+    return hipGetLastError() == hipSuccess ? PG_OK : PG_ERR_HIP;
+}
+int pg_bench_background_wait(pg_handle h) {
+    if (!h) return PG_ERR_ARG;
+    (void)hipSetDevice(h->dev);
+    return hipStreamSynchronize(h->pf_stream) == hipSuccess ? PG_OK : PG_ERR_HIP;
 }
 
 int pg_op_rmsnorm(pg_handle h, float* x_dev, const float* partial_dev, int S, const void* w_dev, void* out_dev, int M, int H,

@@ -249,7 +249,9 @@ __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)
             const f32x4 v4 = *(const f32x4*)(t + row * LD + c4);
             float* p = o + (long)m * N + n;
             // wt: write-through (sc1) -- the slab leaves this XCD's L2 while the kernel runs, not as dirty lines at the boundary
-            if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v4) : "memory");
+            // `s_nop 1` INSIDE the statement: hipcc does not know this is a 128-bit VMEM store, so it neither keeps the data registers
+            // alive nor pads the store-data hazard (a VALU write to them needs 2 wait states); see sk4_store_direct
+            if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v4) : "memory");
             else __builtin_nontemporal_store(v4, (f32x4*)p);
         }
     }
@@ -672,13 +674,13 @@ __device__ __forceinline__ f32x4 sk4_mfma(const bf16x8& a, const bf16x8& wv, con
     if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, a, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wv, c, 0, 0, 0);
 }
-template <int MT, bool SWAP = false>
+template <int MT, bool SWAP = false, int ROWX = 0, bool ROT = false>
 __device__ __forceinline__ void sk4_mfma_chunk(const char* xt, int lr, int g, const bf16x8 (&wc)[4], f32x4 (&acc)[MT]) {
     // A fragment (m-tile mt, k-step i): row mt*16 + lr, logical 16-byte chunk 4i + g, swizzled by lr
-    const char* rp = xt + lr * 256;
+    const char* rp = xt + (lr ^ ROWX) * 256;
     int so[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) so[i] = ((i * 4 + g) ^ lr) << 4;
+    for (int i = 0; i < 4; ++i) so[i] = (ROT ? ((i * 4 + g + lr) & 15) : ((i * 4 + g) ^ lr)) << 4;
     if constexpr (MT == 1) {
         bf16x8 a[4];
 #pragma unroll
@@ -725,7 +727,17 @@ __device__ __forceinline__ void sk4_store_direct(const f32x4 (&acc)[MT], float* 
         const int m = mbase + mt * 16 + lr;
         if (m < M) {
             float* p = o + (long)m * N + n;
-            if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(acc[mt]) : "memory");
+            // ROOT CAUSE of the "stale x piece" failures of rounds 2-3 (found in round 4 by running the kernel under a concurrent memory
+            // load, tools/sk4_load_stress.py): this statement used to be the bare store.  hipcc treats an asm statement as opaque -- it does
+            // not know a 128-bit VMEM store reads its data registers for two more issue slots -- and re-used acc[mt]'s first register for the
+            // NEXT m-tile's row index one instruction later (`v_or_b32 v12, 16, v18` behind `global_store_dwordx4 .., v[12:15]`).  When the
+            // memory pipeline is back-pressured (cold launch, another stream streaming) the store then wrote the clobbered dword for the
+            // lanes it reads last: rows 12-15 of every m-tile except the block's last one (whose store is followed by s_endpgm) lost a
+            // whole split's contribution -- exactly the "rows 12-15 / 28-31 / 44-47" signature that was blamed on the LDS-DMA staging.
+            // With accumulators in AGPRs (another register budget) the data goes through fresh VGPRs and the fault disappears, which is
+            // how it was isolated.  Fix = the ISA's required wait states inside the statement (CDNA guide 5.7: an asm store_dwordx3/x4
+            // ends with `s_nop 1`).
+            if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(acc[mt]) : "memory");
             else __builtin_nontemporal_store(acc[mt], (f32x4*)p);
         }
     }
@@ -778,14 +790,23 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
     const bf16* xsrc[MTW];
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
-        const int r = (w * MTW + j) * 4 + (l >> 4);
+        const int r = ((ABL & 1024) ? (j * 4 + w) : (w * MTW + j)) * 4 + (l >> 4);       // ABL 1024 (hazard screen): wave w owns pieces w, w+4, w+8, ... (one per 4 KiB LDS page)
         const int m = mbase + r;
-        xsrc[j] = x + (long)(m < M ? m : M - 1) * K + split * NCK * SK_BK + (((l & 15) ^ (r & 15)) << 3);
+        // ABL 4096 (hazard screen): rotation swizzle -- LDS position p of row r holds logical chunk (p - r) & 15 -- instead of the XOR swizzle
+        xsrc[j] = x + (long)(m < M ? m : M - 1) * K + split * NCK * SK_BK + (((ABL & 4096) ? (((l & 15) - (r & 15)) & 15) : ((l & 15) ^ (r & 15))) << 3);
     }
     auto issueX = [&](int c) {
         char* slot = smem + (c % XD) * XB + w * (MTW * 1024);
 #pragma unroll
-        for (int j = 0; j < MTW; ++j) glds16(xsrc[j] + c * SK_BK, slot + j * 1024);
+        for (int jj = 0; jj < MTW; ++jj) {
+            const int j = (ABL & 128) ? MTW - 1 - jj : jj;                       // ABL 128 (hazard screen): pieces issued in reverse order
+            if constexpr (ABL & 1024) glds16(xsrc[j] + c * SK_BK, smem + (c % XD) * XB + (j * 4 + w) * 1024);
+            else if constexpr (ABL & 2048) glds16(xsrc[j] + c * SK_BK, slot + (j ^ 3) * 1024);     // ABL 2048 (hazard screen): rows 4j..4j+3 of a 16-row group stored at LDS rows (4j..4j+3) ^ 12
+            else
+            glds16(xsrc[j] + c * SK_BK, slot + j * 1024);
+            if constexpr (ABL & 256) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // ABL 256 (hazard screen): idle issue slots behind every DMA
+        }
+        if constexpr (ABL & 512) glds16(xsrc[0] + c * SK_BK, smem + XD * XB + w * 1024);   // ABL 512 (hazard screen): one more DMA into a dummy 1 KiB per wave behind the group
     };
     bf16x8 wr[WD][4];
     f32x4 acc[MTW];
@@ -812,7 +833,7 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
         }
         wait_vmcnt_w<(ABL & 1) ? 0 : sk4_wait_count_w(c, NCK, XD, WD, MTW)>(wr[c % WD]);      // W(c) landed (younger loads stay in flight)
         stamp();
-        if constexpr (!(ABL & 2)) sk4_mfma_chunk<MTW, (EPI >= 2)>(smem + (c % XD) * XB + wm * (MTW * 4096), lr, g, wr[c % WD], acc);
+        if constexpr (!(ABL & 2)) sk4_mfma_chunk<MTW, (EPI >= 2), (ABL & 2048) ? 12 : 0, (ABL & 4096) != 0>(smem + (c % XD) * XB + wm * (MTW * 4096), lr, g, wr[c % WD], acc);
         else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc[0][0] += (float)wr[c % WD][i][0]; }
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
 unsigned long long* g_sk4_prof = nullptr;       // microbenchmark only
 template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
 static void launch_sk4(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
-    constexpr int XL = XD * MT * 16 * 256, TL = MT * 16 * (4 * 16 + 4) * 4;
+    constexpr int XL = XD * MT * 16 * 256 + ((ABL & 512) ? 4096 * MS : 0), TL = MT * 16 * (4 * 16 + 4) * 4;
     constexpr int LDS = XL > TL ? XL : TL;
     auto kfn = gemm_sk4_kernel<MT, NCK, XD, WD, EPI, OCC, ABL, MS>;
     static bool attr = false;
@@ -897,6 +918,18 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         // 8 waves per block (two row halves): LDS reads of one wave under the MFMAs of the other
         case 130: return sk4_nck<8, 3, 3, 2, 1, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 134: return sk4_nck<4, 3, 3, 2, 2, 0, 2>(s, x, W, out, M, N, K, S) ? 128 : 0;    // 64-row blocks, 8 waves of 2 m-tiles
+        // round 4, hazard screen under background memory load (tools/sk4_load_stress.py): the 64-row production block and protocol variants
+        case 300: return sk4_nck<4, 4, 3, 4, 2, 64>(s, x, W, out, M, N, K, S) ? 128 : 0;         // production copy: chunk c+1 retired at chunk c's barrier
+        case 301: return sk4_nck<4, 4, 3, 4, 2, 64 | 8>(s, x, W, out, M, N, K, S) ? 128 : 0;     // vmcnt(0) in front of every barrier (no counted wait at all)
+        case 302: return sk4_nck<4, 4, 3, 4, 2, 0>(s, x, W, out, M, N, K, S) ? 128 : 0;          // round-2 form: chunk c retired at its own barrier
+        case 303: return sk4_nck<4, 4, 3, 4, 2, 64 | 128>(s, x, W, out, M, N, K, S) ? 128 : 0;   // pieces issued in reverse order
+        case 304: return sk4_nck<4, 4, 3, 4, 2, 64 | 256>(s, x, W, out, M, N, K, S) ? 128 : 0;   // s_nop padding behind every DMA
+        case 305: return sk4_nck<4, 4, 3, 4, 2, 64 | 8 | 512>(s, x, W, out, M, N, K, S) ? 128 : 0;   // a dummy fifth DMA behind every group (+ vmcnt(0) waits: the counted waits do not know it)
+        case 306: return sk4_nck<4, 4, 3, 4, 1, 64>(s, x, W, out, M, N, K, S) ? 128 : 0;         // production copy, one block per CU
+        case 310: return sk4_nck<4, 4, 3, 4, 2, 64 | 4096>(s, x, W, out, M, N, K, S) ? 128 : 0;  // rotation swizzle instead of XOR
+        case 308: return sk4_nck<4, 4, 3, 4, 2, 64 | 1024>(s, x, W, out, M, N, K, S) ? 128 : 0;  // wave w issues pieces w, w+4, w+8, w+12
+        case 309: return sk4_nck<4, 4, 3, 4, 2, 64 | 2048>(s, x, W, out, M, N, K, S) ? 128 : 0;  // LDS row placement permuted (rows ^ 12 within a 16-row group)
+        case 307: return sk4_nck<2, 4, 3, 4, 4, 64>(s, x, W, out, M, N, K, S) ? 128 : 0;         // 32-row blocks (two pieces per wave)
         case 121: return sk4_nck<8, 3, 8, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // deep W ring, direct 16-byte stores
         case 123: return sk4_nck<8, 3, 3, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // shallow W ring, direct stores
         default: return 0;

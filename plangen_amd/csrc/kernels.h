@@ -96,7 +96,16 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
 // partial may be null (S=0).  xn may be null (residual update only).
 template <typename T>
 void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
-                    int M, int H, float eps, int32_t* advance = nullptr);     // advance: *advance += 1 by one thread (decode step counter)
+                    int M, int H, float eps, int32_t* advance = nullptr,      // advance: *advance += 1 by one thread (decode step counter)
+                    uint32_t* prog = nullptr);                                // prog: device-scope ticket bumped by the launch's FIRST thread (weight_prefetch_kernel's pacing signal)
+
+// Run-ahead weight stream through the Infinity Cache (round 4): ONE long-running kernel on a side stream that, paced by the ticket the
+// decode step's norm launches bump, reads the NEXT GEMMs' tiled weights (default cache policy -> resident in the 256 MiB memory-side
+// cache) while the dependent chain on the main stream is in its launch ramps / norm kernels.  A hint only: results never depend on it.
+struct PfMat { const void* base; uint32_t kib; uint32_t regions; };          // kib: size in KiB; regions: consumer blocks (prefetch order interleaves them)
+struct PfLayer { PfMat m[4]; };
+void launch_weight_prefetch(hipStream_t s, const PfLayer* plan_dev, int n_layers, const uint32_t* prog, int steps, int per_step,
+                            int first, int stride, int blocks, int depth, int nt, uint32_t* stats);
 // gather rows: dst fp32 [n,H] = table[ids[idx]]  (table fp32)
 void launch_embed_gather(hipStream_t s, const float* table, const int32_t* ids, const int32_t* src_idx, float* dst,
                          int n, int H, int vocab);

@@ -57,3 +57,33 @@ def get_engine(tiny_cfg, tiny_weights, dtype, **kw):
         e.load_state_dict(tiny_weights)
         _ENGINES[key] = e
     return _ENGINES[key]
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _background_memory_load():
+    """PG_BG_LOAD=<mode> (0 LDS-DMA, 1 LDS-DMA nt, 2 register loads): run the whole GPU suite while a background kernel on another
+    stream streams a private 768 MB buffer (round 4: the decode GEMM's LDS-DMA staging lost pieces under concurrent memory load;
+    every LDS-DMA kernel is screened this way, tools/gpu_under_load.sh).  Off by default."""
+    mode = os.environ.get("PG_BG_LOAD")
+    if mode is None or not torch.cuda.is_available():
+        yield
+        return
+    import ctypes
+    import threading
+    import time
+    from plangen_amd import _lib
+    lib = _lib.load()
+    stop = threading.Event()
+    blocks, depth = int(os.environ.get("PG_BG_BLOCKS", "256")), int(os.environ.get("PG_BG_DEPTH", "16"))
+
+    def pump():
+        while not stop.is_set():
+            if lib.pg_bench_background_done():
+                lib.pg_bench_background(768, 400, blocks, depth, int(mode))
+            time.sleep(0.01)
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    yield
+    stop.set()
+    t.join(timeout=10)
+    lib.pg_bench_background_join()
