@@ -277,6 +277,28 @@ def test_decode_gemm_back_to_back_race_screen(M, N, K, S):
         assert md.value <= 2e-3 * mr.value, (md.value, mr.value)
 
 
+@pytest.mark.parametrize("bg_mode", [2, 0])
+@pytest.mark.parametrize("M,N,K,S", [(128, 2048, 2048, 4), (128, 2048, 5632, 4), (64, 6144, 2048, 2), (64, 11264, 2048, 1), (32, 2048, 5632, 4),
+                                     (16, 6144, 2048, 2)])
+def test_decode_gemm_under_concurrent_memory_load(M, N, K, S, bg_mode):
+    """Round 4: the production decode-GEMM dispatch while ANOTHER STREAM streams 768 MB (bg_mode 2: register loads, 0: LDS-DMA).
+    This is the condition that turned the write-through epilogue's missing store-data wait states (an inline-asm
+    `global_store_dwordx4` whose data register hipcc recycled one instruction later) from a ~0.5 % cold-launch fault into a
+    100 % one: rows 12-15 of every m-tile but the block's last lost a split's contribution (what rounds 2-3 read as a stale
+    LDS-DMA piece).  Before the fix 6 of 6 batches failed here at 32 / 64 / 128 rows; every launch must match the reference kernel."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_hip.so"))
+    lib.pg_bench_skinny_verify.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float)] * 2
+    for _ in range(3):
+        assert lib.pg_bench_background(768, 40, 256, 16, bg_mode) == 0
+        md, mr = C.c_float(0), C.c_float(0)
+        rc = lib.pg_bench_skinny_verify(M, N, K, 2, S, 1, 100, C.byref(md), C.byref(mr))
+        lib.pg_bench_background_join()
+        assert rc == 0
+        assert md.value <= 2e-3 * mr.value, (md.value, mr.value)
+
+
 @pytest.mark.parametrize("M,N,K,iters", [(64, 6144, 2048, 120), (128, 2048, 2048, 60), (128, 2048, 5632, 60), (16, 6144, 2048, 40), (16, 2048, 5632, 40)])
 def test_decode_gemm_cold_launches(tiny_cfg, tiny_weights, M, N, K, iters):
     """(round 3: also the M = 128 narrow-N shapes the bs=64 loop sends to gemm_sk4_kernel<4,...> -- o 128x2048x2048 and down

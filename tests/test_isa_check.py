@@ -31,3 +31,26 @@ def test_lds_dma_protocols_match_the_compiled_code():
     assert v.get("once", 0) == 1             # conv_out halo kernel
     assert set(v) <= {"fifo", "halo_stag", "big", "halo_lock", "once"}         # every verified kernel is on a STRICT spec (no same-phase form left)
     assert r["sk4"]["rc"] == 0 and r["sk4"]["failed"] == 0 and r["sk4"]["checked"] >= 40   # production + bench instantiations of the decode GEMM
+
+
+def test_inline_asm_stores_carry_their_wait_states():
+    """hipcc treats an asm statement as opaque: it neither keeps a 96/128-bit store's data registers alive nor pads the store-data
+    hazard, so the wait states must sit INSIDE the statement (CDNA guide 5.7).  The missing `s_nop 1` behind the decode GEMM's
+    write-through `global_store_dwordx4` was the root cause of the rounds 2-3 "stale x piece" failures.
+    Source-level rule, checked for every inline-asm store in csrc/: a *_store_dwordx3 / x4 is followed by an s_nop >= 1 in the
+    same string."""
+    import glob
+    import re
+    bad, seen = [], 0
+    for f in sorted(glob.glob(os.path.join(ROOT, "plangen_amd", "csrc", "*.h*"))):
+        src = open(f).read()
+        for m in re.finditer(r'asm\s+volatile\s*\(\s*((?:"(?:[^"\\]|\\.)*"\s*)+)', src):
+            text = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', m.group(1)))
+            for st in re.finditer(r"(global|buffer|flat|scratch)_store_dwordx[34]", text):
+                seen += 1
+                tail = text[st.end():]
+                nop = re.search(r"s_nop\s+(\d+)", tail)
+                if not nop or int(nop.group(1)) < 1:
+                    bad.append((os.path.basename(f), src.count("\n", 0, m.start()) + 1))
+    assert seen >= 2, "the write-through epilogue stores were not found: update this check with the code"
+    assert not bad, f"inline-asm wide stores without their wait states: {bad}"
