@@ -360,6 +360,20 @@ def run_rank(args):
         "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": backend,
         "rank_ms_per_step": rank_ms,
     }
+    if not args.tiny and T > 1:
+        # Whole-loop HBM roofline of THIS configuration (SURVEY 8d's definition, so small-batch lines carry their own fraction):
+        # per decode step the weights once (24 layers + gen_head + gen_aligner, compute dtype) + the full K/V of every row at the
+        # PADDED length (no pad skipping, no shared negative prompt -- the survey's conservative byte count), over the 8 TB/s peak.
+        esz_ = 2 if args.dtype == "bf16" else 4
+        w_step = (cfg.n_layers * WEIGHT_PARAMS_LAYER + cfg.gen_head_dim * cfg.hidden + cfg.img_vocab * cfg.gen_head_dim
+                  + cfg.hidden * cfg.img_dim + cfg.hidden * cfg.hidden) * esz_
+        kv_key = cfg.n_layers * 2 * cfg.n_heads * cfg.head_dim * esz_                    # bytes per (row, key)
+        floor_bytes = sum(w_step + 2 * B * (L + t) * kv_key for t in range(1, T))
+        floor_ms = floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
+        out["loop_roofline"] = {"bound": "hbm", "floor_ms": floor_ms, "measured_ms": tm["decode_ms"], "frac": floor_ms / max(tm["decode_ms"], 1e-9),
+                                "algorithmic_gb": floor_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "what": "SURVEY 8d decode-loop byte count of this batch (weights once per step + full K/V of all rows at the padded length) / 8 TB/s, over the measured loop of the last timed step"}
+        out["loop_roofline_frac"] = out["loop_roofline"]["frac"]
 
     if world > 1 and not args.no_shard_check:
         # The gathered token matrix must equal what ONE rank produces for the same seed: all ranks run a short

