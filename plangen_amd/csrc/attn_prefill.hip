@@ -467,7 +467,133 @@ __global__ __launch_bounds__(256) void attn_vit_flash_kernel(const bf16* __restr
         for (int dt = 0; dt < 4; ++dt) ET<bf16>::st(op + dt * 16, oacc[dt][r] * inv);
     }
 }
+// Round 4: K / V^T RESIDENT form.  One block per (image, head) keeps the head's whole K [P][64] and V^T [64][P] in LDS (P = 576: 81 + 73 KiB of
+// the CU's 160 KiB) and walks ALL P queries over it (passes of NW waves x 16 queries; NW = 16: four waves per SIMD hide the per-tile softmax chain): no per-tile staging, no barrier inside the loops --
+// the 64-key tile kernel above staged every K / V tile 9 times per head behind two __syncthreads() each and kept the MFMA pipe busy 11 % of the
+// time.  Grid = heads x images = 1024 blocks = exactly 4 per CU.  Same per-tile arithmetic (order of the online-softmax updates, bf16 P, fp32
+// statistics) as the tile kernel, so the two agree to rounding of identical operations (tests/test_gpu_vision_full.py).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_vit_resident_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt,
+                                                               bf16* __restrict__ o, int P, int C, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VROW = P * 2 + 16;                      // bytes per V^T row (P keys + 16 pad: row stride = 36 dwords mod 64 like VA_ROW)
+    char* sK = smem;                                   // [P][VA_ROW]
+    char* sV = smem + (long)P * VA_ROW;                // [64][VROW]
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
+    const bf16* kbase = qk + (long)b * P * 2 * C + C + head * 64;
+    const bf16* vbase = vt + ((long)b * C + head * 64) * P;
+    // one-time fill: K rows are 128 B in global (8 x 16 B), V^T rows P * 2 B (P / 8 x 16 B); all loads of a round issued before the LDS writes
+    for (int v0 = 0; v0 < P * 8; v0 += 64 * NW * 4) {
+        u32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int v = v0 + j * 64 * NW + tid; if (v < P * 8) t[j] = *(const u32x4*)(kbase + (long)(v >> 3) * 2 * C + (v & 7) * 8); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int v = v0 + j * 64 * NW + tid; if (v < P * 8) *(u32x4*)(sK + (v >> 3) * VA_ROW + (v & 7) * 16) = t[j]; }
+    }
+    const int vpr = P / 8;                             // 16-byte vectors per V^T row
+    for (int v0 = 0; v0 < 64 * vpr; v0 += 64 * NW * 4) {
+        u32x4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int v = v0 + j * 64 * NW + tid; if (v < 64 * vpr) t[j] = *(const u32x4*)(vbase + (long)(v / vpr) * P + (v % vpr) * 8); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int v = v0 + j * 64 * NW + tid; if (v < 64 * vpr) *(u32x4*)(sV + (v / vpr) * VROW + (v % vpr) * 16) = t[j]; }
+    }
+    __syncthreads();
+    for (int qt = 0; qt * 16 * NW < P; ++qt) {
+        const int q0 = qt * 16 * NW + w * 16, myq = q0 + lr;
+        if (q0 >= P) break;                                     // wave-uniform: a partial last pass (P not a multiple of 16 * NW)
+        bf16x8 qf[2];
+        {
+            const bf16* qp = qk + ((long)b * P + myq) * 2 * C + head * 64 + g * 8;
+            qf[0] = *(const bf16x8*)qp; qf[1] = *(const bf16x8*)(qp + 32);
+        }
+        f32x4 oacc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;
+        for (int kb = 0; kb < P; kb += 64) {
+            f32x4 sacc[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                sacc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ds = 0; ds < 2; ++ds) {
+                    const bf16x8 ka = *(const bf16x8*)(sK + (kb + kt * 16 + lr) * VA_ROW + (ds * 32 + g * 8) * 2);
+                    sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ds], sacc[kt], 0, 0, 0);
+                }
+            }
+            float mx = m_run;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sacc[kt][r] *= scale; mx = fmaxf(mx, sacc[kt][r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float alpha = __expf(m_run - mx);
+            float psum = 0.f;
+            bf16x8 pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float p[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p[r] = __expf(sacc[2 * s2][r] - mx);
+                    p[4 + r] = __expf(sacc[2 * s2 + 1][r] - mx);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) psum += p[e];
+                const u32x4 pv = ET<bf16>::pack(p);
+                pf[s2] = *(const bf16x8*)&pv;
+            }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run = l_run * alpha + psum;
+            m_run = mx;
+            if (!__all(alpha == 1.0f)) {                       // the running maximum moved for some query of this wave (x 1.0f is a bitwise no-op: skipping it changes nothing)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) oacc[dt][r] *= a;
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* vr = sV + (dt * 16 + lr) * VROW + kb * 2;
+                    const u32x2 lo = *(const u32x2*)(vr + ((2 * s2) * 16 + g * 4) * 2);
+                    const u32x2 hi = *(const u32x2*)(vr + ((2 * s2 + 1) * 16 + g * 4) * 2);
+                    u32x4 vb; vb.x = lo.x; vb.y = lo.y; vb.z = hi.x; vb.w = hi.y;
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[s2], *(const bf16x8*)&vb, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = 1.f / __shfl(l_run, g * 4 + r, 64);
+            bf16* op = o + ((long)b * P + q0 + g * 4 + r) * C + head * 64 + lr;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) ET<bf16>::st(op + dt * 16, oacc[dt][r] * inv);
+        }
+    }
+}
 // qk [B*P, 2C] (q | k), vt [B][C][P] (V transposed), o [B*P, C]; heads of 64; P % 64 == 0.
 void launch_attn_vit_flash(hipStream_t s, const bf16* qk, const bf16* vt, bf16* o, int B, int P, int C, int NH, float scale) {
+    const long lds = (long)P * VA_ROW + 64L * (P * 2 + 16);
+    if (pg_tune->vit_attn != 1 && lds <= 160 * 1024) {          // K / V^T of one head resident in LDS (vit_attn = 1 selects the 64-key tile kernel for A/B)
+        static bool attr = false;
+        const int nw = pg_tune->vit_attn >= 4 ? pg_tune->vit_attn : 16;      // measured on MI355X (64 images): tower 41.8 / 36.7 / 35.5 / 34.9 ms at 4 / 8 / 12 / 16 waves, tile kernel 37.1
+        if (nw == 4) { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)attn_vit_resident_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a4 = true; }
+            hipLaunchKernelGGL(attn_vit_resident_kernel<4>, dim3(NH, B), dim3(256), (size_t)lds, s, qk, vt, o, P, C, scale); return; }
+        if (nw == 8) { static bool a8 = false; if (!a8) { (void)hipFuncSetAttribute((const void*)attn_vit_resident_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a8 = true; }
+            hipLaunchKernelGGL(attn_vit_resident_kernel<8>, dim3(NH, B), dim3(512), (size_t)lds, s, qk, vt, o, P, C, scale); return; }
+        if (nw == 16) { static bool a16 = false; if (!a16) { (void)hipFuncSetAttribute((const void*)attn_vit_resident_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16 = true; }
+            hipLaunchKernelGGL(attn_vit_resident_kernel<16>, dim3(NH, B), dim3(1024), (size_t)lds, s, qk, vt, o, P, C, scale); return; }
+        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_vit_resident_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(attn_vit_resident_kernel<12>, dim3(NH, B), dim3(768), (size_t)lds, s, qk, vt, o, P, C, scale);
+        return;
+    }
     hipLaunchKernelGGL(attn_vit_flash_kernel, dim3(P / 64, NH, B), dim3(256), 0, s, qk, vt, o, P, C, scale);
 }

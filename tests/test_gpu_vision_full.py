@@ -112,6 +112,14 @@ def test_siglip_fullwidth_bf16_flash_equals_unfused_attention():
     assert d < FEAT_TOL_BF16
 
 
+def test_siglip_fullwidth_resident_attention_equals_tile_attention():
+    """Round 4: `attn_vit_resident_kernel` (K / V^T of a head resident in LDS, all 576 queries per block) performs the same per-tile
+    operations in the same order as the 64-key tile kernel (`vit_attn=1`): features equal bit for bit."""
+    a2, f2 = _run(_engine("bf16"))
+    a1, f1 = _run(_engine("bf16", vit_attn=1))
+    assert torch.equal(f1, f2) and torch.equal(a1, a2)
+
+
 def test_siglip_fullwidth_batch_rows_independent():
     """Image 1 alone == image 1 in the batch of two, bit for bit (no cross-image term anywhere)."""
     e = _engine("bf16")
