@@ -452,6 +452,21 @@ def run_rank(args):
                 tf = fl / (tm["vq_ms"] * 1e-3) / 1e12
                 classes["vq_decode (convs + GroupNorm + AttnBlock)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["vq_ms"],
                                                                         "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
+            # rocprofv3 kernel durations of the same classes (the event-timed intervals above read ~2 us high on short kernels): attached only when
+            # profiles/kernel_classes_b<B>.json was measured on exactly the kernel sources this process runs (tools/trace_classes.py)
+            kj = os.path.join(ROOT, "profiles", "kernel_classes_b%d.json" % B)
+            if os.path.exists(kj):
+                kc = json.load(open(kj))
+                if kc.get("csrc_sha") == csrc_sha():
+                    for cn, ce in kc["classes"].items():
+                        if cn in classes and classes[cn].get("algorithmic_mb_per_launch"):
+                            gbs = classes[cn]["algorithmic_mb_per_launch"] * 1e6 / (ce["avg_us"] * 1e-6) / 1e9
+                            classes[cn].update({"rocprof_avg_launch_us": ce["avg_us"], "rocprof_achieved_gbs": gbs, "rocprof_frac": gbs / HBM_PEAK_GBS})
+                    out["roofline"]["rocprof_classes_source"] = kc.get("source")
+                    if "decode_attention" in kc["classes"]:
+                        a_us = kc["classes"]["decode_attention"]["avg_us"]
+                        out["roofline"]["rocprof_avg_launch_us"] = a_us
+                        out["roofline"]["rocprof_frac"] = out["roofline"]["algorithmic_bytes_per_launch"] / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["classes"] = classes
             dsum = sum(c["ms_sum"] for n, c in cls.items() if n.startswith("decode_gemm") or n == "decode_rmsnorm")
             dby = sum(c["bytes_sum"] for n, c in cls.items() if n.startswith("decode_gemm"))
@@ -527,6 +542,17 @@ def visible_gpus():
         return int(p.stdout.strip().splitlines()[-1])
     except Exception:                                          # noqa: BLE001
         return None
+
+
+def csrc_sha():
+    """Hash of every kernel source (tools/trace_classes.py computes the same): a rocprofv3 class table from other sources is not attached."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "plangen_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kernel_src_sha():

@@ -791,7 +791,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         const Layer& ly = layers[li];
         tic(s); toc(s, TC_EMPTY, 0.0);          // an event pair around nothing: what the instrumentation itself adds to every timed launch
         tic(s);
-        launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps, nullptr, sk ? d_prog : nullptr);
+        launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps, nullptr, (sk && mall_prefetch > 0) ? d_prog : nullptr);
         toc(s, TC_NORM, norm_bytes(S_pend));
         tic(s);
         bool qkv_fused = false;
@@ -841,7 +841,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         else gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk, ly.wo_t);
         toc(s, TC_O, (double)Hh * HDm * wb);
         tic(s);
-        launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps, nullptr, sk ? d_prog : nullptr);
+        launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps, nullptr, (sk && mall_prefetch > 0) ? d_prog : nullptr);
         toc(s, TC_NORM, norm_bytes(S_last));
         bool fused = false;
         tic(s);
@@ -870,7 +870,7 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         S_pend = S_last; slab_pend = slab_last;
     }
     tic(s);
-    launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps, advance, sk ? d_prog : nullptr);
+    launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)norm_w, final_out, M, Hh, cfg.rms_eps, advance, (sk && mall_prefetch > 0) ? d_prog : nullptr);
     toc(s, TC_NORM, norm_bytes(S_pend));
     tc_on = false;
 }

@@ -188,6 +188,8 @@ SPECS = [
     ("conv_halo", r"conv3x3_halo_kernelI.*Lb0ELb[01]E", dict(kind="halo_lock", why="conv_halo=2 option (lock-step waves): vmcnt(4) + two barriers per K tile")),
     ("bench_kernels", r"dma_order_kernel", dict(kind="probe", why="measurement probe (tools/dma_order_probe.py), not on the product path")),
     ("conv_halo", r"conv3x3_out_halo_kernel", dict(kind="once", why="halo patch staged once per tile (conv_out, 128 -> 3 channels)")),
+    ("llm_kernels", r"weight_prefetch_kernel", dict(kind="sink", why="run-ahead weight prefetcher / background-load stressor: the 1 KiB per-wave LDS sink is written by LDS-DMA and never read")),
+    ("chain", r"chain_skel_kernel", dict(kind="probe", why="measured skeleton of the persistent decode chain (tools/chain_skel.py), not on the product path: gathers behind vmcnt(0) + s_barrier, LDS read is a stand-in")),
 ]
 
 
@@ -279,6 +281,12 @@ def main():
                     report.append(f"FAIL {fname}:{short}: " + "; ".join(errs[:3]))
                 else:
                     okc[spec["kind"]] += 1; report.append(f"ok   {fname}:{short}: double buffer, strict form holds ({n} DMA instructions replayed) -- {spec['why']}")
+            elif spec["kind"] == "sink":
+                nread = sum(1 for e in ev if e[0] == "read")
+                if nread:
+                    bad += 1; report.append(f"FAIL {fname}:{short}: {nread} LDS read(s) in a kernel whose LDS-DMA target is declared a write-only sink")
+                else:
+                    okc[spec["kind"]] += 1; report.append(f"ok   {fname}:{short}: LDS-DMA sink never read -- {spec['why']}")
             elif spec["kind"] == "once":
                 # per tile: fill (DMA) -> vmcnt(0) -> barrier -> barrier -> fragment reads -> barrier (patch free).  Linear walk of the tile loop.
                 flat = [e for e in ev if e[0] in ("dma", "wait", "bar", "read")]
