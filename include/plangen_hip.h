@@ -219,6 +219,10 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *                       accumulators); 0 keeps it fp32 like the skip stream
  *   force_swiglu (1)    SwiGLU fused into the decode gate|up GEMM at every batch size
  *   split_target_small / _mid / _big (128 / 256 / 128)   decode split-K block-count targets by row count
+ *   vit_attn (2)        SigLIP attention: 2 = K / V^T of a head resident in LDS, 16 waves per block (round 4); 4 / 8 / 12 / 16 = that kernel
+ *                       with so many waves; 1 = the 64-key tile kernel of rounds 2-3 (bit-identical results)
+ *   mall_prefetch (0)   run-ahead weight prefetcher on its own stream beside the decode loop (measured 5-11 % SLOWER, profiles/r04_b; kept as
+ *                       an option and as the background-load stressor); pf_blocks / pf_depth / pf_nt / pf_first tune it
  * Returns PG_ERR_ARG for an unknown key. */
 int pg_set_option(pg_handle h, const char* key, int64_t value);
 /* Bytes of device memory the handle owns (weights + KV + workspace). */

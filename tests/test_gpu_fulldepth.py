@@ -71,10 +71,10 @@ def test_fulldepth_bf16_teacher_forced():
     stats = {"logit_abs_err_max": float(d.max()), "p99": float(np.percentile(d.numpy(), 99)), "p50": float(np.percentile(d.numpy(), 50)),
              "logit_std": float(torch.from_numpy(g["sel_logits"]).std()), "agreement": float(agree.float().mean()), "margin_median": float(margin.median())}
     print("24-layer bf16 teacher-forced:", json.dumps(stats))
-    # 24 layers of bf16 GEMM inputs under CFG weight 5 (logit std 2.7): bounds = ~2x the values measured on MI355X (round 3)
+    # 24 layers of bf16 GEMM inputs under CFG weight 5 (logit std 2.7): bounds = 1.5x the values measured on MI355X (like the other full-size files)
     assert stats["logit_abs_err_max"] < BF16_MAX and stats["p99"] < BF16_P99, stats
     flips = (~agree) & (margin > 2 * stats["logit_abs_err_max"])
     assert not flips.any()
 
 
-BF16_MAX, BF16_P99 = 0.55, 0.36       # measured on MI355X (round 3): max 0.266, p99 0.177, p50 0.043 at a logit std of 2.75; agreement 93.8 %
+BF16_MAX, BF16_P99 = 0.40, 0.27       # 1.5x measured on MI355X (rounds 3-4): max 0.266, p99 0.177, p50 0.043 at a logit std of 2.75; agreement 93.8 %
