@@ -657,8 +657,9 @@ constexpr int sk4_wait_count_w(int c, int NCK, int XD, int WD, int MT) {
 }
 // W fragment load as OPAQUE asm: the compiler may schedule a plain load from a const __restrict__ pointer across an
 // `asm volatile("" ::: "memory")` fence (nothing can alias it), which silently changes the VMEM issue order the hand-counted vmcnt
-// waits of the v4 kernel assume -- observed as a stale 4-row x piece on a cold first launch.  asm volatile statements keep their
-// program order, so the simulated order of sk4_wait_count() is the order in the instruction stream.
+// waits of the v4 kernel assume.  asm volatile statements keep their program order, so the simulated order of sk4_wait_count() is the
+// order in the instruction stream.  (Round 2 attributed a "stale 4-row x piece on a cold first launch" to this; round 4 found that symptom's
+// real cause in the epilogue's asm store, see sk4_store_direct.  The ordering argument stands on its own.)
 __device__ __forceinline__ void sk4_wload(bf16x8& dst, const bf16* p) {
     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(p) : "memory");
 }
@@ -943,8 +944,9 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
 // 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue instead of the direct one.
 template <int EPI>
 // Every production instantiation retires an x chunk ONE BARRIER BEFORE its first read (ABL bit 64, ring one slot deeper to keep the
-// prefetch distance): reading right behind the barrier that follows the issuing wave's counted wait is not enough on gfx950 -- in ~0.5 %
-// of COLD launches (fresh operands: tools/op_gemm_stress.py) a reader wave saw the old bytes of a wave's LAST 1 KiB piece.
+// prefetch distance): the CDNA guide's staging rule, kept because it is sound and free.  It was introduced in round 2 against wrong rows
+// 12-15 / 28-31 / 44-47 in ~0.5 % of COLD launches; round 4 showed those came from the epilogue's asm store (sk4_store_direct), not from
+// the staging -- the rule never was the fix.
 static bool sk4_prod(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
     // -1 (default): what measured faster IN the decode loop on MI355X (tools/ab_loop.sh, profiles/r02_b_decode_gemm_investigation.md): every class at
     // M <= 64 (48 KiB blocks, 2-3 per CU: loop -3.3 % at bs=32, -6.2 % at bs=8), only the narrow-N slabs at M = 128 (-1.5 %;
