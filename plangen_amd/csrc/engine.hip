@@ -554,7 +554,11 @@ int pg_engine::create() {
     }
     HIPCHK(hipStreamCreateWithFlags(&istream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&istream2, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
+    {   // lowest priority: HIP maps streams onto a few hardware queues; a prefetcher that lands on the decode stream's queue blocks it until its bounded spin gives up
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIPCHK(hipStreamCreateWithPriority(&pf_stream, hipStreamNonBlocking, lo));
+    }
     HIPCHK(hipEventCreateWithFlags(&ev_pf0, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_pf1, hipEventDisableTiming));
     TRY(dalloc(&d_prog, 64));

@@ -102,7 +102,9 @@ __global__ __launch_bounds__(128) void weight_prefetch_kernel(const PfLayer* __r
             p = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (p >= target) break;
             __builtin_amdgcn_s_sleep(16);
-            if (wall_clock64() - t_last > 3000000ull) {         // 30 ms at 100 MHz without a ticket: the loop is over or was aborted
+            // no ticket for 30 ms (100 MHz clock): the loop is over or was aborted.  Before the FIRST ticket the bound is 2 ms: a first ticket that late
+            // means this kernel sits on the decode stream's own hardware queue and is what keeps the loop from starting -- leave at once
+            if (wall_clock64() - t_last > (k == 0 ? 200000ull : 3000000ull)) {
                 if (stats && threadIdx.x == 0 && blockIdx.x == 0) { stats[0] = done_layers; stats[1] = skipped; stats[2] = 1; }
                 return;
             }
