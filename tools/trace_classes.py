@@ -55,7 +55,8 @@ def main():
     a_calls = cls.get("decode_attention", {}).get("calls", 0)
     for c in [c for c in cls if c.startswith("decode_gemm_")]:
         if a_calls and cls[c]["calls"] > 1.5 * a_calls:
-            cls[c + "+merged_%dx" % round(cls[c]["calls"] / a_calls)] = cls.pop(c)
+            e = cls.pop(c)
+            cls[c + "+merged_%dx" % round(e["calls"] / a_calls)] = e
     json.dump({"batch": B, "csrc_sha": csrc_sha(), "source": os.path.basename(md), "what": "rocprofv3 --kernel-trace --stats kernel durations of one bench step (tools/trace_batch.sh)",
                "classes": cls}, open(out, "w"), indent=1)
     print(json.dumps({k: round(v["avg_us"], 2) for k, v in cls.items()}))
