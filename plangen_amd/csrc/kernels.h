@@ -21,6 +21,7 @@ struct PgTune {
     int attn_waves = 0;                                         // 4 / 8 pin the decode-attention block size
     int attn_variant = -1;                                      // unfused attention kernel variant (-1: by mode)
     int prefill_attn = 2;                                       // MFMA prefill attention: 2 = 128-query LDS-DMA / transpose-read kernel, 1 = 64-query kernel
+    int vq_argmin_multi = 1;                                    // VQ nearest-code search: 8 latent vectors per block (0: one per block, rounds 1-3)
     int vit_attn = 2;                                           // SigLIP attention: 2 = K / V^T of a head resident in LDS (round 4), 1 = 64-key tile kernel
     int ln_wave = 1;                                            // SigLIP LayerNorm: wave-per-row register kernel (0: generic block-per-row kernel)
     int wt_store = 0;                                           // v3 decode GEMM slabs with write-through (sc1) stores

@@ -350,8 +350,64 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
         idx[r] = i;
     }
 }
+// Round 4: ZB latent vectors per block -- every codebook entry a thread loads (and its |e|^2) serves ZB distance computations instead of one
+// (the one-vector kernel above re-reads the 512 KiB codebook from L2 once per latent vector: 19 GB for 64 images, 7.8 ms).  The arithmetic
+// of a (vector, code) pair is the SAME expression sequence as above (normalisation, ee, dot, zz + ee - 2 dot, first minimum), so the
+// indices are identical (asserted against the reference fixtures and against the one-vector kernel in tests/test_gpu_ops.py).
+template <int ZB>
+__global__ __launch_bounds__(256) void vq_argmin_multi_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                             int64_t* __restrict__ idx, int n, int V) {
+    constexpr int D = 8;
+    __shared__ float sv[ZB][4]; __shared__ int si[ZB][4];
+    const int r0 = blockIdx.x * ZB, tid = threadIdx.x;
+    float zn[ZB][D], zz[ZB], best[ZB]; int bi[ZB];
+#pragma unroll
+    for (int j = 0; j < ZB; ++j) {
+        const int r = r0 + j < n ? r0 + j : n - 1;
+        float ss = 0.f;
+        for (int d = 0; d < D; ++d) { zn[j][d] = z[(long)r * D + d]; ss += zn[j][d] * zn[j][d]; }
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        zz[j] = 0.f;
+        for (int d = 0; d < D; ++d) { zn[j][d] /= nrm; zz[j] += zn[j][d] * zn[j][d]; }
+        best[j] = INFINITY; bi[j] = 0x7fffffff;
+    }
+    for (int v = tid; v < V; v += 256) {
+        float e[D];
+        const f32x4 e0 = *(const f32x4*)(cb + (long)v * D), e1 = *(const f32x4*)(cb + (long)v * D + 4);
+        e[0] = e0[0]; e[1] = e0[1]; e[2] = e0[2]; e[3] = e0[3]; e[4] = e1[0]; e[5] = e1[1]; e[6] = e1[2]; e[7] = e1[3];
+        float ee = 0.f;
+        for (int d = 0; d < D; ++d) ee += e[d] * e[d];
+#pragma unroll
+        for (int j = 0; j < ZB; ++j) {
+            float dot = 0.f;
+            for (int d = 0; d < D; ++d) dot += zn[j][d] * e[d];
+            const float dist = zz[j] + ee - 2.f * dot;
+            if (dist < best[j]) { best[j] = dist; bi[j] = v; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < ZB; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best[j], o, 64); const int oi = __shfl_xor(bi[j], o, 64);
+            if (ov < best[j] || (ov == best[j] && oi < bi[j])) { best[j] = ov; bi[j] = oi; }
+        }
+        if ((tid & 63) == 0) { sv[j][tid >> 6] = best[j]; si[j][tid >> 6] = bi[j]; }
+    }
+    __syncthreads();
+    if (tid < ZB && r0 + tid < n) {
+        float v = sv[tid][0]; int i = si[tid][0];
+        for (int k = 1; k < 4; ++k) if (sv[tid][k] < v || (sv[tid][k] == v && si[tid][k] < i)) { v = sv[tid][k]; i = si[tid][k]; }
+        idx[r0 + tid] = i;
+    }
+}
 void launch_vq_argmin(hipStream_t s, const float* z, const float* codebook, int64_t* idx, int n, int D, int V) {
     if (n <= 0) return;
+    if (D == 8 && pg_tune->vq_argmin_multi && n >= 64) {
+        constexpr int ZB = 8;
+        hipLaunchKernelGGL(vq_argmin_multi_kernel<ZB>, dim3((n + ZB - 1) / ZB), dim3(256), 0, s, z, codebook, idx, n, V);
+        return;
+    }
     hipLaunchKernelGGL(vq_argmin_kernel, dim3(n), dim3(256), 0, s, z, codebook, idx, D, V);
 }
 

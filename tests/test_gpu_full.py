@@ -346,3 +346,22 @@ def test_vq16_full_size_encoder_vs_reference_fixture(dtype):
         print(f"bf16 full-size VQ encode: {1 - bad.mean():.3f} of 576 indices equal; largest reference gap at a mismatch {gap[bad].max() if bad.any() else 0:.4f} (median gap {np.median(gap):.4f})")
         assert bad.mean() < 0.10 and (not bad.any() or gap[bad].max() < 0.016)      # measured on MI355X: 4.5 % differ, all at reference gaps <= 0.0079 (median gap 0.024)
     e.close()
+
+
+def test_vq_argmin_multi_vector_kernel_equals_one_vector_kernel():
+    """Round 4: `vq_argmin_multi_kernel` (8 latent vectors per block) against the one-vector kernel of rounds 1-3 on full-size VQ-16
+    encodes of 4 random images (2 304 latent vectors x 16 384 codes): identical indices (same per-pair arithmetic, first minimum)."""
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    cfg = PlanGenConfig.janus_pro_1b()
+    e = Engine(cfg, dtype="bf16", max_rows=2, max_prompt=1, max_new=1, max_images=4, with_vq_encoder=True)
+    e.init_synthetic(seed=0)
+    g = torch.Generator().manual_seed(17)
+    x = (torch.rand(4, 3, cfg.img_size, cfg.img_size, generator=g) * 2 - 1).to(torch.bfloat16)
+    outs = []
+    for multi in (1, 0, 1):
+        e.set_option("vq_argmin_multi", multi)
+        outs.append(e.vq_encode(x).cpu())
+    e.close()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert len(torch.unique(outs[0])) > 100
