@@ -178,7 +178,7 @@ struct pg_engine {
     int mall_prefetch = 0, pf_blocks = 256, pf_depth = 16, pf_nt = 0, pf_first = 2;
     uint32_t* d_prog = nullptr; PfLayer* d_pfplan = nullptr; uint32_t* d_pfstats = nullptr; bool pf_plan_ok = false;
     hipStream_t pf_stream = nullptr; hipEvent_t ev_pf0 = nullptr, ev_pf1 = nullptr; bool pf_live = false;
-    int32_t* d_row_order = nullptr; bool lpt_order = true; bool order_valid = false; int order_rows = 0;
+    int32_t* d_row_order = nullptr; bool lpt_order = true; int lpt_snake = 0; bool order_valid = false; int order_rows = 0;
     SeqState seq() const { return SeqState{d_len, d_pos_off, d_ndec, d_tok_row, d_tok_j, shared_len, shared_row, (lpt_order && order_valid && kv_row_off == 0 && R == order_rows) ? d_row_order : nullptr}; }
 
     int create();
@@ -939,6 +939,11 @@ int pg_engine::prefill(const int32_t* ids_dev, const void* emb_dev, int emb_dtyp
         std::stable_sort(s_ord, s_ord + R_, [&](int a, int b) {
             const int ka = h_len[a] - ((shared_len > 0 && (a & 1)) ? shared_len : 0), kb = h_len[b] - ((shared_len > 0 && (b & 1)) ? shared_len : 0);
             return ka > kb; });
+        // snake order (round 4, option lpt_snake = chunk size, 0 = plain longest-first): all 16 * R blocks of the attention launch are resident at
+        // once (8 per CU), so "longest first" balances nothing by itself; what matters is which ranks share a CU.  Reversing every second chunk
+        // of the sorted list makes the ranks a CU receives (a stride-`chunk` pick) sum to the same length to first order.
+        if (lpt_snake > 1)
+            for (int c0 = lpt_snake; c0 + lpt_snake <= R_; c0 += 2 * lpt_snake) std::reverse(s_ord + c0, s_ord + c0 + lpt_snake);
         order_valid = true; order_rows = R_;
     }
     HIPCHK(hipEventRecord(ev_p0, s));
@@ -1642,6 +1647,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "vq_mid_bf16")) { h->mid_bf16 = value != 0; return PG_OK; }
     if (!strcmp(key, "attn_waves")) { h->tune.attn_waves = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "lpt_order")) { h->lpt_order = value != 0; h->tune_epoch++; return PG_OK; }
+    if (!strcmp(key, "lpt_snake")) { h->lpt_snake = (int)value; h->tune_epoch++; return PG_OK; }      // takes effect at the next pg_prefill
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "prefill_res_epi")) { h->prefill_res_epi = value != 0; return PG_OK; }
     if (!strcmp(key, "prefill_rope_epi")) { h->prefill_rope_epi = value != 0; return PG_OK; }
