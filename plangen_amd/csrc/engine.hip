@@ -1613,6 +1613,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "pf_first")) { h->pf_first = (int)value; return PG_OK; }
     if (!strcmp(key, "gemm256")) { h->tune.gemm256 = (int)value; return PG_OK; }
     if (!strcmp(key, "conv_halo")) { h->tune.conv_halo = (int)value; return PG_OK; }
+    if (!strcmp(key, "attn_pair")) { h->tune.attn_pair = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "vit_attn")) { h->tune.vit_attn = (int)value; return PG_OK; }
     if (!strcmp(key, "vq_argmin_multi")) { h->tune.vq_argmin_multi = (int)value; return PG_OK; }
     if (!strcmp(key, "wt_store")) { h->tune.wt_store = (int)value; h->tune_epoch++; return PG_OK; }

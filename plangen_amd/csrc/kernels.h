@@ -19,6 +19,7 @@ struct PgTune {
     int gemm256 = 1;                                            // 256x256 eight-phase MFMA GEMM for large shapes
     int conv_halo = 1;                                          // direct halo-tile 3x3 convolution (2: lock-step variant)
     int attn_waves = 0;                                         // 4 / 8 pin the decode-attention block size
+    int attn_pair = 0;                                          // decode attention: two (row, head) items per block, longest + shortest (round 4 experiment)
     int attn_variant = -1;                                      // unfused attention kernel variant (-1: by mode)
     int prefill_attn = 2;                                       // MFMA prefill attention: 2 = 128-query LDS-DMA / transpose-read kernel, 1 = 64-query kernel
     int vq_argmin_multi = 1;                                    // VQ nearest-code search: 8 latent vectors per block (0: one per block, rounds 1-3)

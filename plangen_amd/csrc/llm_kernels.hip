@@ -411,8 +411,16 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
     __shared__ __attribute__((aligned(16))) float s_q[128];
     __shared__ float s_k[128], s_v[128];
     __shared__ float s_new;
-    const int head = blockIdx.x, row = st.row_order ? st.row_order[blockIdx.y] : blockIdx.y;
+    // ABL bit 32 (round 4, `attn_pair`): the grid has M / 2 rows of blocks and every block processes TWO (row, head) items -- rank y of the
+    // longest-first order, then rank M - 1 - y -- so all blocks carry (longest + shortest) ~ the same number of keys and the second item's
+    // prologue runs while the CU's other blocks stream (the one-item launch has every block in its prologue at once and a tail of short rows)
+    constexpr int NIT = (ABL & 32) ? 2 : 1;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int head = blockIdx.x;
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+    const int yi = it == 0 ? (int)blockIdx.y : (int)(2 * gridDim.y - 1 - blockIdx.y);
+    const int row = st.row_order ? st.row_order[yi] : yi;
     const int grp = l / LPK, lk = l % LPK;
     const int slot = st.len[row] + *st.n_dec;
     const int nprev = slot < slots ? slot : slots - 1;
@@ -651,6 +659,8 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
             *(f32x4*)dst = *(const f32x4*)src;
         }
     }
+    if constexpr (NIT > 1) __syncthreads();          // the append and the merge have read this item's LDS state
+    }
 }
 template <typename T>
 void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc,
@@ -674,6 +684,8 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
             default: ATT_LAUNCH(6, 4, 23); break;
         }
     } else if (small) ATT_LAUNCH(5, 8, 16);
+    else if (pg_tune->attn_pair && (M & 1) == 0 && st.row_order)
+        hipLaunchKernelGGL((attn_decode_fused_kernel<T, 6, 4, 16 | 32>), dim3(nh, M / 2), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, nh, slots, max_pos, scale);
     else ATT_LAUNCH(6, 4, 16);
 #undef ATT_LAUNCH
 }
