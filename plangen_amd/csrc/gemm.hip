@@ -931,6 +931,11 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 308: return sk4_nck<4, 4, 3, 4, 2, 64 | 1024>(s, x, W, out, M, N, K, S) ? 128 : 0;  // wave w issues pieces w, w+4, w+8, w+12
         case 309: return sk4_nck<4, 4, 3, 4, 2, 64 | 2048>(s, x, W, out, M, N, K, S) ? 128 : 0;  // LDS row placement permuted (rows ^ 12 within a 16-row group)
         case 307: return sk4_nck<2, 4, 3, 4, 4, 64>(s, x, W, out, M, N, K, S) ? 128 : 0;         // 32-row blocks (two pieces per wave)
+        // round 4: W register-ring depth of the wide-N production block (64 rows x 128 columns, 8 waves, tiled W) -- bytes in flight per block
+        case 400: return sk3_prod_nck<4, 0, 8, true, 2>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;
+        case 401: return sk3_prod_nck<4, 0, 8, true, 3>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;
+        case 402: return sk3_prod_nck<4, 0, 8, true, 4>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;
+        case 403: return sk3_prod_nck<4, 0, 8, true, 6>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;
         case 121: return sk4_nck<8, 3, 8, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // deep W ring, direct 16-byte stores
         case 123: return sk4_nck<8, 3, 3, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // shallow W ring, direct stores
         default: return 0;
