@@ -377,6 +377,22 @@ void launch_attn_prefill_flash(hipStream_t s, const bf16* qbuf, bf16* obuf, cons
 // V^T from the [B][C][P] tensor the encoder's V projection already writes (key-contiguous rows: staged
 // without a transpose).  Scores are scaled in fp32 after the MFMA, like the softmax kernel it replaces.
 #define VA_ROW 144           // bytes per LDS row (64 x bf16 + 16 pad)
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap / v_permlane32_swap (gfx950) exchange
+// rows between two copies of the value -- with both operands the same register the pair it returns is (even rows duplicated, odd rows duplicated)
+// resp. (low half duplicated, high half duplicated) -- instead of two ds_bpermute round trips through the LDS crossbar per reduction
+// (the flash kernels' per-tile softmax chain is latency-bound).  Same operands, commutative operation: bit-identical to the __shfl_xor form.
+__device__ __forceinline__ float rows_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __global__ __launch_bounds__(256) void attn_vit_flash_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt,
                                                             bf16* __restrict__ o, int P, int C, float scale) {
     __shared__ __attribute__((aligned(16))) char sK[64 * VA_ROW];
@@ -395,6 +411,7 @@ __global__ __launch_bounds__(256) void attn_vit_flash_kernel(const bf16* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = scale * 1.44269504088896340736f;
     for (int kb = 0; kb < P; kb += 64) {
         __syncthreads();
 #pragma unroll
@@ -414,14 +431,17 @@ __global__ __launch_bounds__(256) void attn_vit_flash_kernel(const bf16* __restr
                 sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ds], sacc[kt], 0, 0, 0);
             }
         }
-        float mx = m_run;
+        // scores stay UNSCALED in the accumulators: the running maximum is kept in units of log2 (m_run = max(s) * scale * log2 e) and every
+        // probability is ONE fma + ONE v_exp_f32: 2^(s * c - m) with c = scale * log2 e (round 4: was scale-multiply, subtract, log2e-multiply, exp)
+        float mraw = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sacc[kt][r] *= scale; mx = fmaxf(mx, sacc[kt][r]); }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float alpha = __expf(m_run - mx);
+            for (int r = 0; r < 4; ++r) mraw = fmaxf(mraw, sacc[kt][r]);
+        mraw = fmaxf(mraw, __shfl_xor(mraw, 16, 64));
+        mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+        const float mx = fmaxf(m_run, mraw * c2);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mx);
         float psum = 0.f;
         bf16x8 pf[2];
 #pragma unroll
@@ -429,8 +449,8 @@ __global__ __launch_bounds__(256) void attn_vit_flash_kernel(const bf16* __restr
             float p[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                p[r] = __expf(sacc[2 * s2][r] - mx);
-                p[4 + r] = __expf(sacc[2 * s2 + 1][r] - mx);
+                p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[2 * s2][r], c2, -mx));
+                p[4 + r] = __builtin_amdgcn_exp2f(fmaf(sacc[2 * s2 + 1][r], c2, -mx));
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) psum += p[e];
@@ -512,6 +532,7 @@ __global__ __launch_bounds__(64 * NW) void attn_vit_resident_kernel(const bf16* 
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         float m_run = -INFINITY, l_run = 0.f;
+        const float c2 = scale * 1.44269504088896340736f;
         for (int kb = 0; kb < P; kb += 64) {
             f32x4 sacc[4];
 #pragma unroll
@@ -523,14 +544,14 @@ __global__ __launch_bounds__(64 * NW) void attn_vit_resident_kernel(const bf16* 
                     sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ds], sacc[kt], 0, 0, 0);
                 }
             }
-            float mx = m_run;
+            float mraw = -INFINITY;                        // same arithmetic as the tile kernel: unscaled scores, log2-domain running maximum
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { sacc[kt][r] *= scale; mx = fmaxf(mx, sacc[kt][r]); }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float alpha = __expf(m_run - mx);
+                for (int r = 0; r < 4; ++r) mraw = fmaxf(mraw, sacc[kt][r]);
+            mraw = rows_max(mraw);
+            const float mx = fmaxf(m_run, mraw * c2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - mx);
             float psum = 0.f;
             bf16x8 pf[2];
 #pragma unroll
@@ -538,16 +559,15 @@ __global__ __launch_bounds__(64 * NW) void attn_vit_resident_kernel(const bf16* 
                 float p[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    p[r] = __expf(sacc[2 * s2][r] - mx);
-                    p[4 + r] = __expf(sacc[2 * s2 + 1][r] - mx);
+                    p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[2 * s2][r], c2, -mx));
+                    p[4 + r] = __builtin_amdgcn_exp2f(fmaf(sacc[2 * s2 + 1][r], c2, -mx));
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) psum += p[e];
                 const u32x4 pv = ET<bf16>::pack(p);
                 pf[s2] = *(const bf16x8*)&pv;
             }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
+            psum = rows_sum(psum);
             l_run = l_run * alpha + psum;
             m_run = mx;
             if (!__all(alpha == 1.0f)) {                       // the running maximum moved for some query of this wave (x 1.0f is a bitwise no-op: skipping it changes nothing)

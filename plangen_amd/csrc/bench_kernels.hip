@@ -441,3 +441,34 @@ extern "C" int pg_bench_background_done() {        // 1 when the background kern
     return hipStreamQuery(g_bg_stream) == hipSuccess ? 1 : 0;
 }
 extern "C" int pg_bench_background_join() { return g_bg_stream && hipStreamSynchronize(g_bg_stream) != hipSuccess ? -2 : 0; }
+
+
+// Exhaustive check of the hardware f32 -> bf16 conversion (common.h) against the software round-to-nearest-even of rounds 1-3: all 2^32 bit
+// patterns; NaN inputs only have to stay NaN.  Returns the number of differing non-NaN patterns (expected 0) and of NaNs that did not stay NaN.
+__global__ void bf16_cvt_check_kernel(unsigned long long* out) {
+    unsigned long long bad = 0, badnan = 0;
+    const unsigned long long n = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float f = __uint_as_float((uint32_t)i);
+        const uint32_t hw = f32_to_bf16_bits(f), sw = f32_to_bf16_bits_sw(f);
+        const uint32_t pk = pack_bf16x2(f, -f);
+        if (((uint32_t)i & 0x7fffffffu) > 0x7f800000u) { if ((hw & 0x7fffu) <= 0x7f80u) ++badnan; }
+        else { if (hw != sw || (pk & 0xffffu) != sw || (pk >> 16) != (sw ^ 0x8000u)) ++bad; }
+    }
+    if (bad) atomicAdd(out, bad);
+    if (badnan) atomicAdd(out + 1, badnan);
+}
+extern "C" int pg_bench_bf16_cvt_check(unsigned long long* mismatches, unsigned long long* nan_lost) {
+    unsigned long long* d;
+    if (hipMalloc((void**)&d, 16) != hipSuccess) return -2;
+    hipMemset(d, 0, 16);
+    hipLaunchKernelGGL(bf16_cvt_check_kernel, dim3(4096), dim3(256), 0, 0, d);
+    hipDeviceSynchronize();
+    const int rc = hipGetLastError() == hipSuccess ? 0 : -2;
+    unsigned long long h[2] = {0, 0};
+    hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (mismatches) *mismatches = h[0];
+    if (nan_lost) *nan_lost = h[1];
+    return rc;
+}

@@ -17,14 +17,23 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b16) { return __uint_as_float(b16 << 16); }
 __device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+// Software round-to-nearest-even (rounds 1-3: ~6 VALU operations per element).  Kept as the reference of the exhaustive check below.
+__device__ __forceinline__ uint32_t f32_to_bf16_bits_sw(float f) {
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN -> quiet NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+// Round 4: gfx950 converts in hardware (v_cvt_pk_bf16_f32, one instruction per PAIR, round-to-nearest-even).  Identical to the software form
+// for every non-NaN fp32 bit pattern (pg_bench_bf16_cvt_check walks all 2^32, tests/test_gpu_ops.py); NaNs stay NaNs (payload may differ).
+typedef __attribute__((ext_vector_type(2))) __bf16 pg_bf16x2_t;
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+    const __bf16 b = (__bf16)f;
+    return (uint32_t)__builtin_bit_cast(unsigned short, b);
+}
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    pg_bf16x2_t r; r[0] = (__bf16)lo; r[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 // Element-type traits: T = float (PG_F32 mode) or bf16 (PG_BF16 mode).

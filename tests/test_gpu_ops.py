@@ -329,3 +329,15 @@ def test_decode_gemm_cold_launches(tiny_cfg, tiny_weights, M, N, K, iters):
         if d.max().item() >= tol:
             idx = (d >= tol).nonzero()
             raise AssertionError((it, d.max().item(), sorted(set(idx[:, 0].tolist()))[:16], sorted(set((idx[:, 1] // 16).tolist()))[:16]))
+
+
+def test_hardware_bf16_conversion_equals_software_rne_for_every_float():
+    """Round 4: every fp32 -> bf16 conversion of the library (epilogues, norms, attention outputs, P in the flash kernels, VQ activations) is
+    gfx950's v_cvt_pk_bf16_f32 instead of a 6-instruction software round-to-nearest-even.  All 2^32 bit patterns: identical for every
+    non-NaN input (single and packed form), NaNs stay NaNs."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_hip.so"))
+    bad, nan_lost = C.c_ulonglong(1), C.c_ulonglong(1)
+    assert lib.pg_bench_bf16_cvt_check(C.byref(bad), C.byref(nan_lost)) == 0
+    assert bad.value == 0 and nan_lost.value == 0, (bad.value, nan_lost.value)
