@@ -491,6 +491,9 @@ def run_rank(args):
                 head_ms = sum(c["ms_sum"] / max(1, c["launches"]) for n, c in cls.items()          # one event interval per step each
                               if n in ("decode_gen_head", "decode_cfg_sampler"))
                 g_ms = t2["decode_ms"] / Tn - head_ms
+                if g_ms <= 0:                      # tiny shapes under heavy external load: the event-timed head can exceed the replayed step; report the step itself
+                    g_ms = t2["decode_ms"] / Tn
+                    ph["head_not_subtracted"] = True
                 w_step = dby / nsteps_timed
                 ph.update({"ms_per_step": g_ms, "weight_gbs": w_step / (g_ms * 1e-3) / 1e9, "frac": w_step / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "method": "decode step replayed without its attention launches (%d steps, same launch mode as the timed region) minus event-timed gen_head + sampler "
