@@ -60,9 +60,11 @@ def synth_prompts(B, L, vocab, pad_id, seed):
 
 
 def cpu_baseline(L, steps_sample, threads):
-    """The CPU oracle (torch-CPU fp32 restatement of the reference, kind 'port') on a bounded
-    sample of the same workload: 1 image (2 CFG rows), prefill at L, ``steps_sample`` decode
-    steps, 1 VQ decode; extrapolated to 576 steps."""
+    """The CPU oracle (torch-CPU fp32 restatement of the reference, kind 'port') on a bounded sample of the same workload: 1 image
+    (2 CFG rows), prefill at L, decode steps timed at FIVE contexts spread over the loop (L + {0, 144, 288, 432, 560}: the K/V the steps
+    read grows from 257 to 831 keys, so the first steps alone would understate a step), 1 VQ decode; the per-step time is the mean over
+    the five contexts, extrapolated to 576 steps.  ``threads`` is the measured-fastest thread count; an all-core figure is reported
+    beside it from a 2-layer slice of one step (SURVEY 8d asks for "all physical cores", which is far slower for these skinny GEMMs)."""
     import torch
     from oracle import ref_cpu as R
     torch.set_num_threads(threads)
@@ -70,6 +72,9 @@ def cpu_baseline(L, steps_sample, threads):
     W = R.make_weights(cfg, seed=0, with_lm_head=False)
     ids, mask = synth_prompts(1, L, cfg.vocab, 3, 0)
     mask = torch.cat([mask, torch.ones((2, cfg.img_tokens), dtype=torch.int32)], dim=1)
+    offsets = [0, 144, 288, 432, 560]
+    per_ctx = max(2, steps_sample // len(offsets))
+    g = torch.Generator().manual_seed(0)
     with torch.no_grad():
         emb = R.embed_tokens(W, ids)
         t0 = time.time()
@@ -77,24 +82,54 @@ def cpu_baseline(L, steps_sample, threads):
         hid, cache = R.llama_forward(W, cfg, emb, mask, pos)
         t_prefill = time.time() - t0
         x = R.prepare_gen_img_embeds(W, torch.zeros(2, dtype=torch.long))[:, None]
-        t0 = time.time()
-        for i in range(steps_sample):
-            p = torch.full((2, 1), L + i)
-            hid, cache = R.llama_forward(W, cfg, x, mask, p, cache)
-            logits = R.gen_head(W, hid[:, -1])
-            mixed = logits[1::2] + 5.0 * (logits[0::2] - logits[1::2])
-            tok = torch.argmax(mixed, -1)
-            x = R.prepare_gen_img_embeds(W, torch.stack([tok, tok], 1).view(-1))[:, None]
-        t_step = (time.time() - t0) / steps_sample
+        step_ms = {}
+        for off in offsets:
+            # a cache of L + off keys: the prefilled prompt + random K/V of the right shape (step time does not depend on the values)
+            grow = L + off - cache.length()
+            if grow > 0:
+                for i in range(cfg.n_layers):
+                    pad_kv = torch.randn((2, cfg.n_heads, grow, cfg.head_dim), generator=g) * 0.5
+                    cache.k[i] = torch.cat([cache.k[i], pad_kv], dim=2)
+                    cache.v[i] = torch.cat([cache.v[i], pad_kv], dim=2)
+            t0 = time.time()
+            for i in range(per_ctx):
+                p = torch.full((2, 1), L + off + i)
+                hid, cache = R.llama_forward(W, cfg, x, mask, p, cache)
+                logits = R.gen_head(W, hid[:, -1])
+                mixed = logits[1::2] + 5.0 * (logits[0::2] - logits[1::2])
+                tok = torch.argmax(mixed, -1)
+                x = R.prepare_gen_img_embeds(W, torch.stack([tok, tok], 1).view(-1))[:, None]
+            step_ms[off] = (time.time() - t0) / per_ctx * 1e3
+        t_step = sum(step_ms.values()) / len(step_ms) * 1e-3
         codes = torch.randint(0, cfg.img_vocab, (1, cfg.img_tokens))
         t0 = time.time()
         R.vq_decode_code(W, cfg, codes)
         t_vq = time.time() - t0
+        # all cores, bounded: ONE decode step through a 2-layer slice of the same weights (x 12 = the 24-layer stack; gen_head excluded)
+        import dataclasses
+        ncpu = os.cpu_count() or 1
+        all_core = None
+        if ncpu != threads:
+            torch.set_num_threads(ncpu)
+            cfg2 = dataclasses.replace(cfg, n_layers=2)
+            c2 = R.KVCache([cache.k[0][:, :, :L + 288].clone(), cache.k[1][:, :, :L + 288].clone()],
+                           [cache.v[0][:, :, :L + 288].clone(), cache.v[1][:, :, :L + 288].clone()])
+            p = torch.full((2, 1), L + 288)
+            R.llama_forward(W, cfg2, x, mask, p, c2)                    # warm-up (thread pool start)
+            t0 = time.time()
+            for i in range(2):
+                R.llama_forward(W, cfg2, x, mask, torch.full((2, 1), L + 289 + i), c2)
+            all_core = {"cores": ncpu, "ms_per_step_est": (time.time() - t0) / 2 * 12 * 1e3,
+                        "what": "2 decode steps through layers 0-1 at context L+288, x12 (gen_head excluded)"}
+            torch.set_num_threads(threads)
     per_image = t_prefill + 576 * t_step + t_vq
-    return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 image (2 CFG rows): prefill L={L} {t_prefill:.2f}s, {steps_sample} decode steps "
-                      f"{t_step * 1e3:.0f} ms/step extrapolated to 576, VQ decode {t_vq:.2f}s",
-            "image_tokens_per_s": 576.0 / (t_prefill + 576 * t_step)}
+    out = {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
+           "sample": f"1 image (2 CFG rows): prefill L={L} {t_prefill:.2f}s, {per_ctx} decode steps at each of the contexts L+{offsets} "
+                     f"(ms/step {[round(step_ms[o]) for o in offsets]}, mean {t_step * 1e3:.0f}) extrapolated to 576, VQ decode {t_vq:.2f}s",
+           "image_tokens_per_s": 576.0 / (t_prefill + 576 * t_step), "ms_per_step_by_context": {str(L + o): step_ms[o] for o in offsets}}
+    if all_core:
+        out["all_cores"] = all_core
+    return out
 
 
 def parse_args(argv=None):
@@ -113,6 +148,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-shard-check", action="store_true")
+    ap.add_argument("--no-gemm-phase", action="store_true", help="skip the second (libplangen_diag.so) handle that times the decode step without attention")
+    ap.add_argument("--diag-opt", action="append", default=[], help="MEASUREMENT ONLY: key=value for pg_diag_set_option; the whole run then uses "
+                    "libplangen_diag.so and the line says so (tools/ab_loop.sh)")
     ap.add_argument("--cpu-steps", type=int, default=64)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--time-stride", type=int, default=8, help="instrumented pass: time every n-th decode step")
@@ -152,6 +190,7 @@ def spawn_ranks(n, argv, poll_s=0.2, grace_s=5.0):
     def _on_signal(signum, frame):
         raise _Terminated(signum)
     old_handlers = {sg: signal.signal(sg, _on_signal) for sg in (signal.SIGTERM, signal.SIGHUP)}
+    old_int = signal.getsignal(signal.SIGINT)
 
     def _pdeathsig():
         try:
@@ -160,17 +199,18 @@ def spawn_ranks(n, argv, poll_s=0.2, grace_s=5.0):
         except Exception:
             pass
 
-    for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PG_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=out0 if r == 0 else None, start_new_session=True, preexec_fn=_pdeathsig))
     rcs = [None] * n
     failed = None
     interrupted = False
     try:
+        # the spawn loop is INSIDE the try: a signal during rank start-up must reach the kill path with the ranks started so far
+        for r in range(n):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, PG_BENCH_CHILD="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else None, start_new_session=True, preexec_fn=_pdeathsig))
         while any(rc is None for rc in rcs):
             for r, p in enumerate(procs):
                 if rcs[r] is None:
@@ -182,32 +222,36 @@ def spawn_ranks(n, argv, poll_s=0.2, grace_s=5.0):
             time.sleep(poll_s)
     except BaseException:                                      # Ctrl-C / SIGTERM of the launcher: the ranks live in their own sessions and would survive it
         interrupted = True
-        failed = next((r for r in range(n) if rcs[r] is None), 0)
-    if failed is not None:
-        sys.stderr.write(("bench.py: launcher interrupted" if interrupted else f"bench.py: rank {failed} exited with rc {rcs[failed]}") + "; terminating the other ranks\n")
-        live = [p for r, p in enumerate(procs) if p.poll() is None]
-        for p in live:
-            try:
-                os.killpg(p.pid, signal.SIGTERM)          # the rank's own process group (start_new_session): exact PIDs, no pattern
-            except ProcessLookupError:
-                pass
-        t_end = time.time() + grace_s
-        for p in live:
-            try:
-                p.wait(timeout=max(0.0, t_end - time.time()))
-            except subprocess.TimeoutExpired:
+        failed = next((r for r in range(len(procs)) if rcs[r] is None), 0)
+    try:
+        if failed is not None:
+            # a second signal must not abort the kill path (the SIGKILL escalation would never run): ignored until the ranks are gone
+            for sg in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+                signal.signal(sg, signal.SIG_IGN)
+            sys.stderr.write(("bench.py: launcher interrupted" if interrupted else f"bench.py: rank {failed} exited with rc {rcs[failed]}") + "; terminating the other ranks\n")
+            live = [p for p in procs if p.poll() is None]
+            for p in live:
                 try:
-                    os.killpg(p.pid, signal.SIGKILL)
+                    os.killpg(p.pid, signal.SIGTERM)          # the rank's own process group (start_new_session): exact PIDs, no pattern
                 except ProcessLookupError:
                     pass
-                p.wait()
-        rcs = [p.returncode for p in procs]
-        if interrupted:
-            for sg, h in old_handlers.items():
-                signal.signal(sg, h)
-            return 130
-    for sg, h in old_handlers.items():
-        signal.signal(sg, h)
+            t_end = time.time() + grace_s
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.0, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    try:
+                        os.killpg(p.pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
+                    p.wait()
+            rcs = [p.returncode for p in procs] + [None] * (n - len(procs))
+            if interrupted:
+                return 130
+    finally:
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
+        signal.signal(signal.SIGINT, old_int)
     out0.seek(0)
     sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
@@ -252,6 +296,158 @@ def launch_check(args, world, rank):
     return 0
 
 
+def loop_roofline(cfg, dtype, B, L, T, pad, decode_ms, uncond_shared):
+    """Whole-loop HBM roofline of THIS configuration, two byte counts over the 8 TB/s peak:
+      algorithmic_gb  SURVEY 8d's definition -- per decode step the weights once (24 layers + gen_head + gen_aligner, compute dtype) + the full
+                      K/V of every row at the PADDED length (no pad skipping, no shared negative prompt): the survey's conservative count;
+      moved_gb        what the kernels have to stream: left-pad slots are never stored or read, and a batch-constant negative prompt is
+                      stored once and its K/V read from HBM once per (layer, step) -- the other uncond rows hit it in L2.  The savings are
+                      real wins, but the time-over-bytes fraction of the hardware is the ``moved_*`` one."""
+    esz_ = 2 if dtype == "bf16" else 4
+    w_step = (cfg.n_layers * WEIGHT_PARAMS_LAYER + cfg.gen_head_dim * cfg.hidden + cfg.img_vocab * cfg.gen_head_dim
+              + cfg.hidden * cfg.img_dim + cfg.hidden * cfg.hidden) * esz_
+    kv_key = cfg.n_layers * 2 * cfg.n_heads * cfg.head_dim * esz_                    # bytes per (row, key)
+    floor_bytes = sum(w_step + 2 * B * (L + t) * kv_key for t in range(1, T))
+    real = [L - p for p in pad]
+    cond_keys = sum(real[0::2])
+    if uncond_shared:
+        unc_prompt_keys, unc_rows = real[1], B                                         # the prompt once, every row's private suffix
+    else:
+        unc_prompt_keys, unc_rows = sum(real[1::2]), B
+    moved = sum(w_step + (cond_keys + B * t + unc_prompt_keys + unc_rows * t) * kv_key for t in range(1, T))
+    floor_ms = floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
+    moved_ms = moved / (HBM_PEAK_GBS * 1e9) * 1e3
+    return {"bound": "hbm", "floor_ms": floor_ms, "measured_ms": decode_ms, "frac": floor_ms / max(decode_ms, 1e-9),
+            "algorithmic_gb": floor_bytes / 1e9, "moved_gb": moved / 1e9, "moved_frac": moved_ms / max(decode_ms, 1e-9),
+            "moved_gbs": moved / 1e9 / max(decode_ms * 1e-3, 1e-12), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "what": "frac = SURVEY 8d decode-loop byte count of this batch (weights once per step + full K/V of all rows at the padded length) / 8 TB/s over the "
+                    "measured loop of the last timed step; moved_* = the bytes the kernels actually stream (pads skipped, shared negative prompt read once)"}
+
+
+def instrumented_pass(eng, args, cfg, B, L, T, ids, pad, tm):
+    """Right after the timed region, same batch, eager launches: HIP events ON THE LAUNCH STREAM around every decode kernel class on every
+    --time-stride-th step.  Dominant kernel = decode attention (HBM-bound K/V streaming).  Returns the ``roofline`` object (or None)."""
+    import torch
+    eng.set_option("time_attn", 1)
+    eng.set_option("time_stride", args.time_stride)
+    eng.prefill(ids, pad, position_mode=0)
+    eng.decode_image_tokens(T=T, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=99)
+    torch.cuda.synchronize()
+    ta = eng.timing()
+    cls = eng.class_timing()
+    eng.set_option("time_attn", 0)
+    if not ta["attn_launches"]:
+        return None
+    ach = ta["attn_bytes_sum"] / (ta["attn_ms_sum"] * 1e-3) / 1e9
+    kname = "attn_decode_fused_kernel"
+    # PMC traffic cannot be collected from inside this process: it comes from separate rocprofv3 --pmc passes of this same command
+    # (tools/pmc_traffic.py writes profiles/pmc_attn.json with the kernel symbol and the source hash it was measured at).  A ratio
+    # measured on another kernel symbol / source is not applied.
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "pmc_attn.json")
+    if os.path.exists(pj):
+        pm = json.load(open(pj))
+        if kname in pm.get("kernel_symbol", "") and pm.get("kernel_src_sha") == kernel_src_sha():
+            traffic = pm["traffic_per_algorithmic_byte"] * ta["attn_bytes_sum"] / ta["attn_launches"]
+    rf = {"bound": "hbm", "kernel": kname + " (RoPE + KV append + decode attention)",
+          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+          "launches": ta["attn_launches"], "avg_launch_us": ta["attn_ms_sum"] / ta["attn_launches"] * 1e3,
+          "algorithmic_bytes_per_launch": ta["attn_bytes_sum"] / ta["attn_launches"],
+          "decode_loop_share": ta["attn_ms_sum"] * args.time_stride / max(ta["decode_ms"], 1e-9),
+          "timed_every_nth_step": args.time_stride}
+    # Event timing of SHORT kernels is pessimistic: an event pair around nothing already costs a few us in this eager pass
+    # ("event_pair_overhead_us"; measured ~4.7 us, about half of it lands inside a timed interval).  "avg_launch_us" is
+    # the raw event interval; the rocprofv3 --kernel-trace averages of the replayed loop are in profiles/.
+    empty = cls.get("empty_event_pair", {"ms_sum": 0.0, "launches": 0})
+    rf["event_pair_overhead_us"] = empty["ms_sum"] / empty["launches"] * 1e3 if empty["launches"] else None
+    classes = {}
+    for name, c in cls.items():
+        if not c["launches"] or name == "empty_event_pair":
+            continue
+        gbs = c["bytes_sum"] / (c["ms_sum"] * 1e-3) / 1e9
+        classes[name] = {"bound": "hbm", "avg_launch_us": c["ms_sum"] / c["launches"] * 1e3,
+                         "algorithmic_mb_per_launch": c["bytes_sum"] / c["launches"] / 1e6,
+                         "achieved_gbs": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": c["launches"]}
+    if not args.tiny and T == cfg.img_tokens:
+        # MFMA-bound phases, whole-phase times of the LAST TIMED step (HIP events inside the library):
+        ntok = sum(L - p for i, p in enumerate(pad) if i % 2 == 0) + (L - pad[1])        # shared uncond prompt prefilled once
+        lens = [L - p for i, p in enumerate(pad) if i % 2 == 0] + [L - pad[1]]
+        fl = 2.0 * ntok * cfg.n_layers * WEIGHT_PARAMS_LAYER + sum(4.0 * cfg.n_layers * cfg.hidden * n * (n + 1) / 2 for n in lens)
+        tf = fl / (tm["prefill_ms"] * 1e-3) / 1e12
+        classes["prefill (packed GEMMs + flash attention)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["prefill_ms"],
+                                                               "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
+        fl = VQ_DECODE_GFLOP_PER_IMAGE * 1e9 * B
+        tf = fl / (tm["vq_ms"] * 1e-3) / 1e12
+        classes["vq_decode (convs + GroupNorm + AttnBlock)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["vq_ms"],
+                                                                "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
+    # rocprofv3 kernel durations of the same classes (the event-timed intervals above read ~2 us high on short kernels): attached only when
+    # profiles/kernel_classes_b<B>.json was measured on exactly the kernel sources this process runs (tools/trace_classes.py)
+    kj = os.path.join(ROOT, "profiles", "kernel_classes_b%d.json" % B)
+    if os.path.exists(kj):
+        kc = json.load(open(kj))
+        if kc.get("csrc_sha") == csrc_sha():
+            for cn, ce in kc["classes"].items():
+                if cn in classes and classes[cn].get("algorithmic_mb_per_launch"):
+                    gbs = classes[cn]["algorithmic_mb_per_launch"] * 1e6 / (ce["avg_us"] * 1e-6) / 1e9
+                    classes[cn].update({"rocprof_avg_launch_us": ce["avg_us"], "rocprof_achieved_gbs": gbs, "rocprof_frac": gbs / HBM_PEAK_GBS})
+            rf["rocprof_classes_source"] = kc.get("source")
+            if "decode_attention" in kc["classes"]:
+                a_us = kc["classes"]["decode_attention"]["avg_us"]
+                rf["rocprof_avg_launch_us"] = a_us
+                rf["rocprof_frac"] = rf["algorithmic_bytes_per_launch"] / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+    rf["classes"] = classes
+    rf["_class_sums"] = cls
+    return rf
+
+
+def gemm_norm_phase(args, cfg, B, L, T, ids, pad, cls, device):
+    """The decode GEMM + RMSNorm phase (everything of a layer except attention), two measurements:
+      events_*   sum of the per-launch HIP-event intervals of the instrumented pass (one event pair, ~4.6 us, per launch on ~150 short
+                 launches per step: pessimistic);
+      (plain)    the SAME decode step replayed, as the timed region launches it, WITHOUT its 24 attention launches -- a switch that exists
+                 only in libplangen_diag.so (``skip_attn``; results are garbage by construction) on a second handle with the same weights,
+                 minus the event-timed gen_head + sampler share (5 launches per step)."""
+    import torch
+    from plangen_amd.engine import Engine
+    dsum = sum(c["ms_sum"] for n, c in cls.items() if n.startswith("decode_gemm") or n == "decode_rmsnorm")
+    dby = sum(c["bytes_sum"] for n, c in cls.items() if n.startswith("decode_gemm"))
+    if dsum <= 0:
+        return None
+    nsteps_timed = max(1, cls["decode_gemm_qkv"]["launches"] // cfg.n_layers)
+    ph = {"events_weight_gbs": dby / (dsum * 1e-3) / 1e9, "events_frac": dby / (dsum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+          "events_ms_per_step": dsum / nsteps_timed}
+    try:
+        deng = Engine(cfg, dtype=args.dtype, max_rows=2 * B, max_prompt=L, max_new=cfg.img_tokens, max_images=B, device=device, diag=True)
+    except Exception as ex:                                   # noqa: BLE001 -- the diagnostics library is optional for a bench line
+        ph["skip_attn_pass"] = "unavailable: " + repr(ex)[:200]
+        return ph
+    try:
+        deng.init_synthetic(seed=0)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            deng.set_option(k, int(v))
+        Tn = min(T, 96)
+        deng.set_diag_option("skip_attn", 1)
+        for _ in range(2):
+            deng.prefill(ids, pad, position_mode=0)
+            deng.decode_image_tokens(T=Tn, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=7)
+            torch.cuda.synchronize()
+        t2 = deng.timing()
+    finally:
+        deng.close()
+    head_ms = sum(c["ms_sum"] / max(1, c["launches"]) for n, c in cls.items()          # one event interval per step each
+                  if n in ("decode_gen_head", "decode_cfg_sampler"))
+    g_ms = t2["decode_ms"] / Tn - head_ms
+    if g_ms <= 0:                      # tiny shapes under heavy external load: the event-timed head can exceed the replayed step; report the step itself
+        g_ms = t2["decode_ms"] / Tn
+        ph["head_not_subtracted"] = True
+    w_step = dby / nsteps_timed
+    ph.update({"ms_per_step": g_ms, "weight_gbs": w_step / (g_ms * 1e-3) / 1e9, "frac": w_step / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "method": "decode step replayed without its attention launches on a libplangen_diag.so handle (%d steps, same launch mode as the timed region) minus "
+                         "event-timed gen_head + sampler (%.3f ms/step); events_* = sum of per-launch HIP-event intervals" % (Tn, head_ms)})
+    return ph
+
+
 # ------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -293,11 +489,14 @@ def run_rank(args):
         return 2
     B = G // world
     T = args.tokens or cfg.img_tokens
-    eng = Engine(cfg, dtype=args.dtype, max_rows=2 * B, max_prompt=L, max_new=cfg.img_tokens, max_images=B, device=local)
+    eng = Engine(cfg, dtype=args.dtype, max_rows=2 * B, max_prompt=L, max_new=cfg.img_tokens, max_images=B, device=local, diag=bool(args.diag_opt))
     eng.init_synthetic(seed=0)
     for kv in args.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))
+    for kv in args.diag_opt:
+        k, v = kv.split("=")
+        eng.set_diag_option(k, int(v))
 
     # rank 0 collates the global batch and broadcasts it over RCCL; every rank keeps its contiguous slice
     if rank == 0:
@@ -359,20 +558,10 @@ def run_rank(args):
         "device_gb": eng.device_bytes() / 2 ** 30,
         "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": backend,
         "rank_ms_per_step": rank_ms,
+        "library": "libplangen_diag.so (MEASUREMENT BUILD: --diag-opt %s)" % " ".join(args.diag_opt) if args.diag_opt else "libplangen_hip.so",
     }
     if not args.tiny and T > 1:
-        # Whole-loop HBM roofline of THIS configuration (SURVEY 8d's definition, so small-batch lines carry their own fraction):
-        # per decode step the weights once (24 layers + gen_head + gen_aligner, compute dtype) + the full K/V of every row at the
-        # PADDED length (no pad skipping, no shared negative prompt -- the survey's conservative byte count), over the 8 TB/s peak.
-        esz_ = 2 if args.dtype == "bf16" else 4
-        w_step = (cfg.n_layers * WEIGHT_PARAMS_LAYER + cfg.gen_head_dim * cfg.hidden + cfg.img_vocab * cfg.gen_head_dim
-                  + cfg.hidden * cfg.img_dim + cfg.hidden * cfg.hidden) * esz_
-        kv_key = cfg.n_layers * 2 * cfg.n_heads * cfg.head_dim * esz_                    # bytes per (row, key)
-        floor_bytes = sum(w_step + 2 * B * (L + t) * kv_key for t in range(1, T))
-        floor_ms = floor_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
-        out["loop_roofline"] = {"bound": "hbm", "floor_ms": floor_ms, "measured_ms": tm["decode_ms"], "frac": floor_ms / max(tm["decode_ms"], 1e-9),
-                                "algorithmic_gb": floor_bytes / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "what": "SURVEY 8d decode-loop byte count of this batch (weights once per step + full K/V of all rows at the padded length) / 8 TB/s, over the measured loop of the last timed step"}
+        out["loop_roofline"] = loop_roofline(cfg, args.dtype, B, L, T, pad, tm["decode_ms"], uncond_shared)
         out["loop_roofline_frac"] = out["loop_roofline"]["frac"]
 
     if world > 1 and not args.no_shard_check:
@@ -398,107 +587,17 @@ def run_rank(args):
         fence()
 
     if not args.no_roofline and rank == 0:
-        # Instrumented pass right after the timed region: same batch, eager launches, hipEvents on the launch
-        # stream around every decode kernel class on every --time-stride-th step (the timed region replays a hipGraph,
-        # which cannot carry events between nodes).  Dominant kernel = decode attention (HBM-bound K/V streaming).
-        eng.set_option("time_attn", 1)
-        eng.set_option("time_stride", args.time_stride)
-        eng.prefill(ids, pad, position_mode=0)
-        eng.decode_image_tokens(T=T, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=99)
-        torch.cuda.synchronize()
-        ta = eng.timing()
-        cls = eng.class_timing()
-        eng.set_option("time_attn", 0)
-        if ta["attn_launches"]:
-            ach = ta["attn_bytes_sum"] / (ta["attn_ms_sum"] * 1e-3) / 1e9
-            kname = "attn_decode_fused_kernel"
-            # PMC traffic cannot be collected from inside this process: it comes from separate rocprofv3 --pmc
-            # passes of this same command (tools/pmc_traffic.py writes profiles/pmc_attn.json with the kernel symbol
-            # and the commit it was measured at).  A ratio measured on another kernel symbol is not applied.
-            traffic = None
-            pj = os.path.join(ROOT, "profiles", "pmc_attn.json")
-            if os.path.exists(pj):
-                pm = json.load(open(pj))
-                if kname in pm.get("kernel_symbol", "") and pm.get("kernel_src_sha") == kernel_src_sha():
-                    traffic = pm["traffic_per_algorithmic_byte"] * ta["attn_bytes_sum"] / ta["attn_launches"]
-            out["roofline"] = {"bound": "hbm", "kernel": kname + " (RoPE + KV append + decode attention)",
-                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "launches": ta["attn_launches"], "avg_launch_us": ta["attn_ms_sum"] / ta["attn_launches"] * 1e3,
-                               "algorithmic_bytes_per_launch": ta["attn_bytes_sum"] / ta["attn_launches"],
-                               "decode_loop_share": ta["attn_ms_sum"] * args.time_stride / max(ta["decode_ms"], 1e-9),
-                               "timed_every_nth_step": args.time_stride}
-            # Event timing of SHORT kernels is pessimistic: an event pair around nothing already costs a few us in this eager pass
-            # ("event_pair_overhead_us"; measured ~4.7 us, about half of it lands inside a timed interval).  "avg_launch_us" is
-            # the raw event interval; the rocprofv3 --kernel-trace averages of the replayed loop are in profiles/.
-            empty = cls.get("empty_event_pair", {"ms_sum": 0.0, "launches": 0})
-            out["roofline"]["event_pair_overhead_us"] = empty["ms_sum"] / empty["launches"] * 1e3 if empty["launches"] else None
-            classes = {}
-            for name, c in cls.items():
-                if not c["launches"] or name == "empty_event_pair":
-                    continue
-                gbs = c["bytes_sum"] / (c["ms_sum"] * 1e-3) / 1e9
-                classes[name] = {"bound": "hbm", "avg_launch_us": c["ms_sum"] / c["launches"] * 1e3,
-                                 "algorithmic_mb_per_launch": c["bytes_sum"] / c["launches"] / 1e6,
-                                 "achieved_gbs": gbs, "frac": gbs / HBM_PEAK_GBS, "launches": c["launches"]}
-            if not args.tiny and T == cfg.img_tokens:
-                # MFMA-bound phases, whole-phase times of the LAST TIMED step (HIP events inside the library):
-                ntok = sum(L - p for i, p in enumerate(pad) if i % 2 == 0) + (L - pad[1])        # shared uncond prompt prefilled once
-                lens = [L - p for i, p in enumerate(pad) if i % 2 == 0] + [L - pad[1]]
-                fl = 2.0 * ntok * cfg.n_layers * WEIGHT_PARAMS_LAYER + sum(4.0 * cfg.n_layers * cfg.hidden * n * (n + 1) / 2 for n in lens)
-                tf = fl / (tm["prefill_ms"] * 1e-3) / 1e12
-                classes["prefill (packed GEMMs + flash attention)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["prefill_ms"],
-                                                                       "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
-                fl = VQ_DECODE_GFLOP_PER_IMAGE * 1e9 * B
-                tf = fl / (tm["vq_ms"] * 1e-3) / 1e12
-                classes["vq_decode (convs + GroupNorm + AttnBlock)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["vq_ms"],
-                                                                        "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
-            # rocprofv3 kernel durations of the same classes (the event-timed intervals above read ~2 us high on short kernels): attached only when
-            # profiles/kernel_classes_b<B>.json was measured on exactly the kernel sources this process runs (tools/trace_classes.py)
-            kj = os.path.join(ROOT, "profiles", "kernel_classes_b%d.json" % B)
-            if os.path.exists(kj):
-                kc = json.load(open(kj))
-                if kc.get("csrc_sha") == csrc_sha():
-                    for cn, ce in kc["classes"].items():
-                        if cn in classes and classes[cn].get("algorithmic_mb_per_launch"):
-                            gbs = classes[cn]["algorithmic_mb_per_launch"] * 1e6 / (ce["avg_us"] * 1e-6) / 1e9
-                            classes[cn].update({"rocprof_avg_launch_us": ce["avg_us"], "rocprof_achieved_gbs": gbs, "rocprof_frac": gbs / HBM_PEAK_GBS})
-                    out["roofline"]["rocprof_classes_source"] = kc.get("source")
-                    if "decode_attention" in kc["classes"]:
-                        a_us = kc["classes"]["decode_attention"]["avg_us"]
-                        out["roofline"]["rocprof_avg_launch_us"] = a_us
-                        out["roofline"]["rocprof_frac"] = out["roofline"]["algorithmic_bytes_per_launch"] / (a_us * 1e-6) / 1e9 / HBM_PEAK_GBS
-            out["roofline"]["classes"] = classes
-            dsum = sum(c["ms_sum"] for n, c in cls.items() if n.startswith("decode_gemm") or n == "decode_rmsnorm")
-            dby = sum(c["bytes_sum"] for n, c in cls.items() if n.startswith("decode_gemm"))
-            if dsum > 0:
-                nsteps_timed = max(1, cls["decode_gemm_qkv"]["launches"] // cfg.n_layers)
-                ph = {"events_weight_gbs": dby / (dsum * 1e-3) / 1e9, "events_frac": dby / (dsum * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "events_ms_per_step": dsum / nsteps_timed}
-                # The event-timed figure carries one event pair (~4.6 us) per launch on ~150 short launches per step.  Second, precise
-                # measurement: the SAME decode step replayed (as the timed region launches it) WITHOUT its 24 attention launches ("skip_attn", results
-                # are garbage by construction) -- what is left is the GEMM + norm phase plus gen_head / sampler, whose event-timed
-                # share (5 launches per step) is subtracted.
-                Tn = min(T, 96)
-                eng.set_option("skip_attn", 1)
-                eng.prefill(ids, pad, position_mode=0)
-                eng.decode_image_tokens(T=Tn, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=7)
-                torch.cuda.synchronize()
-                eng.prefill(ids, pad, position_mode=0)
-                eng.decode_image_tokens(T=Tn, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=7)
-                torch.cuda.synchronize()
-                t2 = eng.timing()
-                eng.set_option("skip_attn", 0)
-                head_ms = sum(c["ms_sum"] / max(1, c["launches"]) for n, c in cls.items()          # one event interval per step each
-                              if n in ("decode_gen_head", "decode_cfg_sampler"))
-                g_ms = t2["decode_ms"] / Tn - head_ms
-                if g_ms <= 0:                      # tiny shapes under heavy external load: the event-timed head can exceed the replayed step; report the step itself
-                    g_ms = t2["decode_ms"] / Tn
-                    ph["head_not_subtracted"] = True
-                w_step = dby / nsteps_timed
-                ph.update({"ms_per_step": g_ms, "weight_gbs": w_step / (g_ms * 1e-3) / 1e9, "frac": w_step / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "method": "decode step replayed without its attention launches (%d steps, same launch mode as the timed region) minus event-timed gen_head + sampler "
-                                     "(%.3f ms/step); events_* = sum of per-launch HIP-event intervals" % (Tn, head_ms)})
-                out["roofline"]["decode_gemm_norm_phase"] = ph
+        rf = instrumented_pass(eng, args, cfg, B, L, T, ids, pad, tm)
+        if rf:
+            out["roofline"] = rf
+            if not args.tiny and not args.no_gemm_phase:
+                # the decode step WITHOUT its attention launches needs the diagnostics library (no switch of libplangen_hip.so can make a handle
+                # skip work): the product engine is released first, a second handle in libplangen_diag.so replays the same steps
+                eng.close()
+                ph = gemm_norm_phase(args, cfg, B, L, T, ids, pad, rf.pop("_class_sums"), local)
+                if ph:
+                    rf["decode_gemm_norm_phase"] = ph
+            rf.pop("_class_sums", None)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
@@ -506,7 +605,9 @@ def run_rank(args):
         # (ms/step: 16 thr 89, 32 thr 144, 64 thr 298, 256 thr 42 466)
         out["cpu_baseline"] = cpu_baseline(L, args.cpu_steps, min(args.cpu_threads, os.cpu_count() or 1))
     if rank == 0 and world == 1 and not args.no_rccl_selftest and not args.tiny:
-        out["rccl_selftest"] = rccl_selftest()
+        # under rocprofv3 the child would inherit the profiler's preload and write a second results database into the same directory
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        out["rccl_selftest"] = {"rccl_one_rank": "skipped under a profiler"} if profiled else rccl_selftest()
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
@@ -559,13 +660,14 @@ def csrc_sha():
 
 
 def kernel_src_sha():
-    """Identity of the decode-attention kernel SOURCE a PMC ratio belongs to (hash of the kernel's text in llm_kernels.hip,
-    from its signature to its launcher): a ratio measured on another version of the kernel is not applied."""
+    """Identity of the decode-attention kernel SOURCE a PMC ratio belongs to (hash of csrc/attn_decode.h, the kernel template, + the
+    production launcher in llm_kernels.hip): a ratio measured on another version of the kernel is not applied."""
     import hashlib
-    src = open(os.path.join(ROOT, "plangen_amd", "csrc", "llm_kernels.hip")).read()
-    a = src.find("void attn_decode_fused_kernel(")
-    b = src.find("void launch_attn_decode_fused(")
-    return hashlib.sha256(src[a:b].encode()).hexdigest()[:16]
+    d = os.path.join(ROOT, "plangen_amd", "csrc")
+    src = open(os.path.join(d, "llm_kernels.hip")).read()
+    a = src.find("void launch_attn_decode_fused(")
+    b = src.find("template void launch_attn_decode_fused<float>")
+    return hashlib.sha256((open(os.path.join(d, "attn_decode.h")).read() + src[a:b]).encode()).hexdigest()[:16]
 
 
 def main(argv=None):

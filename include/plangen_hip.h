@@ -185,44 +185,45 @@ int pg_get_timing(pg_handle h, pg_timing* out);
  * (+ split-K reduce + residual), gen_head, CFG sampler, 8: event pairs around nothing (instrumentation overhead); *bytes_sum = algorithmic HBM bytes of the timed launches
  * (weights once per launch; K/V once per launch).  Returns PG_ERR_ARG past the last class. */
 int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum, int* launches, double* bytes_sum);
-/* Tuning / measurement switches (defaults in parentheses), PER HANDLE; none changes results except where noted:
- *   time_attn (0)       per-launch HIP events around every decode kernel class (eager loop); time_stride (1): every n-th step
- *   rng_image_offset (0)  global index of this handle's image 0: prompt-sharded ranks sample exactly what one big batch would
- *   allow_partial_weights (0)  run although required tensors were never loaded (they read as zeros)
- *   stream_gemm (-1 auto)  bit mask of the decode GEMM classes on the v4 kernel (x tile by LDS-DMA): 1 wide-N slabs, 2 narrow-N
- *                       slabs, 4 SwiGLU gate|up, 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue; 0 = v3 everywhere;
- *                       128 = v3 wide-N blocks of 64 columns / 4 waves instead of 128 columns / 8 waves
- *   wt_store (0)        v3 split-K slabs with write-through (sc1) stores
- *   use_graph (0)       replay the decode step as a hipGraph (one launch per step from the host; env PG_USE_GRAPH=1).  Off by default:
- *                       same-stream launches of the ~175 kernels of a step measure 1-3 % faster than graph replay
- *   share_uncond (1)    prefill / store a batch-constant negative prompt once
- *   flash_prefill (1)   MFMA flash attention for prefill (0: per-query streaming kernel)
- *   fuse_rope (1)       RoPE + KV append inside the decode-attention kernel
- *   skip_attn (0)       MEASUREMENT ONLY: decode steps without their attention launches (results are garbage); bench.py times the
- *                       graph-replayed GEMM + norm phase with it
- *   lanes (1)           2: two row-range lanes on two streams
- *   cu_split (0)        with lanes=2: complementary CU masks on the lane streams (1-4: mask patterns)
- *   lpt_order (1)       longest rows first in the decode-attention launch
- *   attn_variant, attn_waves (0; 4 pins 4-wave blocks)   decode-attention kernel variants
- *   uncond_shared_hint  ONE-SHOT, consumed by the next pg_prefill: 1 = the caller has compared the ids on the host (its collate built them,
- *                       plangen_base.py:672-686 replicates one negative prompt) and every odd row equals row 1 -> no device probe, pg_prefill does
- *                       not synchronise; 0 = they differ; -1 (default) = probe on the device (one 4-byte read + stream sync)
- *   prefill_attn (2)    MFMA prefill attention: 2 = 128 queries per block, K/V by LDS-DMA, V through the LDS transpose read; 1 = 64-query kernel
- *   prefill_rope_epi (1) prefill QKV projection: RoPE + KV-cache write in the 256x256 GEMM's epilogue when the packed batch takes that kernel
- *                       (plangen_base.py:571 -> LlamaAttention.forward); 0 = GEMM -> fp32 q|k|v -> RoPE / KV-fill kernel.  Same bits either way.
- *   prefill_res_epi (1) prefill o_proj / down_proj: residual add in the GEMM epilogue; 0 = fp32 slab folded in by the norm kernel.  Same bits.
- *   ln_wave (1)         SigLIP LayerNorm (width 1024): wave-per-row register kernel; 0 = block-per-row kernel
- *   gemm256 (1)         256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)
- *   conv_halo (1)       direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: off)
- *   gn_fuse (1)         GroupNorm statistics from the producing convolution's epilogue (halo-tile convolutions)
- *   vq_mid_bf16 (1)     bf16 mode: the tensor between a ResnetBlock's two convolutions is bf16 (statistics from the fp32
- *                       accumulators); 0 keeps it fp32 like the skip stream
- *   force_swiglu (1)    SwiGLU fused into the decode gate|up GEMM at every batch size
- *   split_target_small / _mid / _big (128 / 256 / 128)   decode split-K block-count targets by row count
- *   vit_attn (2)        SigLIP attention: 2 = K / V^T of a head resident in LDS, 16 waves per block (round 4); 4 / 8 / 12 / 16 = that kernel
- *                       with so many waves; 1 = the 64-key tile kernel of rounds 2-3 (bit-identical results)
- *   mall_prefetch (0)   run-ahead weight prefetcher on its own stream beside the decode loop (measured 5-11 % SLOWER, profiles/r04_b; kept as
- *                       an option and as the background-load stressor); pf_blocks / pf_depth / pf_nt / pf_first tune it
+/* Switches of the product library (defaults in parentheses), PER HANDLE.  NONE changes what a handle returns: they are measurement taps,
+ * per-call hints, and A/B fallbacks that produce the same results (each is equality-tested on the GPU).  Experiments that lost their
+ * measurement were removed in round 5; kernel-variant tables, timing ablations and the "decode step without attention" measurement
+ * mode live in a SEPARATE library (libplangen_diag.so: pg_diag_set_option, pg_bench_*; csrc/diag_api.hip) that this header does not cover.
+ *   measurement
+ *     time_attn (0)          per-launch HIP events around every decode kernel class (eager loop) -> pg_get_timing / pg_get_class_timing
+ *     time_stride (1)        ... on every n-th decode step only
+ *   per-call hints
+ *     rng_image_offset (0)   global index of this handle's image 0: prompt-sharded ranks sample exactly what one big batch would
+ *     uncond_shared_hint     ONE-SHOT, consumed by the next pg_prefill: 1 = the caller has compared the ids on the host (its collate built
+ *                            them, plangen_base.py:672-686 replicates one negative prompt) and every odd row equals row 1 -> no device
+ *                            probe, pg_prefill does not synchronise; 0 = they differ; -1 (default) = probe on the device (one 4-byte
+ *                            read + stream sync)
+ *     allow_partial_weights (0)  run although required tensors were never loaded (they read as zeros)
+ *   decode loop
+ *     share_uncond (1)       prefill / store a batch-constant negative prompt once (0: every uncond row keeps a private copy)
+ *     use_graph (0)          replay the decode step as a hipGraph (one launch per step from the host; env PG_USE_GRAPH=1).  Off by
+ *                            default: same-stream launches of the ~175 kernels of a step measure 1-3 % faster than graph replay
+ *     lanes (1)              2: two row-range lanes on two streams (measured 6 % slower at bs=64; kept as a documented fallback)
+ *     stream_gemm (-1 auto)  bit mask of the decode GEMM classes on the v4 kernel (x tile by LDS-DMA): 1 wide-N slabs, 2 narrow-N slabs,
+ *                            4 SwiGLU gate|up, 8 the M <= 16 kernels, 16 SwiGLU through the LDS-transposed epilogue; 0 = v3 everywhere;
+ *                            128 = v3 wide-N blocks of 64 columns / 4 waves instead of 128 columns / 8 waves
+ *     split_target_big (128) decode split-K block-count target at >= 96 rows (per-handle isolation is tested with it)
+ *   prefill
+ *     flash_prefill (1)      MFMA flash attention for prefill (0: per-query streaming kernel)
+ *     prefill_attn (2)       MFMA prefill attention: 2 = 128 queries per block, K/V by LDS-DMA, V through the LDS transpose read; 1 = 64-query kernel
+ *     prefill_rope_epi (1)   QKV projection: RoPE + KV-cache write in the 256x256 GEMM's epilogue when the packed batch takes that kernel
+ *                            (plangen_base.py:571 -> LlamaAttention.forward); 0 = GEMM -> fp32 q|k|v -> RoPE / KV-fill kernel.  Same bits.
+ *     prefill_res_epi (1)    o_proj / down_proj: residual add in the GEMM epilogue; 0 = fp32 slab folded in by the norm kernel.  Same bits.
+ *     gemm256 (1)            256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)
+ *   VQ-16
+ *     conv_halo (1)          direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: implicit-GEMM kernel)
+ *     vq_mid_bf16 (1)        bf16 mode: the tensor between a ResnetBlock's two convolutions is bf16 (statistics from the fp32
+ *                            accumulators); 0 keeps it fp32 like the skip stream
+ *     vq_argmin_multi (1)    nearest-code search: 8 latent vectors per block (0: one per block); identical indices
+ *   SigLIP
+ *     vit_attn (2)           2 = K / V^T of a head resident in LDS, 16 waves per block; 4 / 8 / 12 / 16 = that kernel with so many waves;
+ *                            1 = the 64-key tile kernel of rounds 2-3 (bit-identical results)
+ *     ln_wave (1)            LayerNorm (width 1024): wave-per-row register kernel; 0 = block-per-row kernel
  * Returns PG_ERR_ARG for an unknown key. */
 int pg_set_option(pg_handle h, const char* key, int64_t value);
 /* Bytes of device memory the handle owns (weights + KV + workspace). */

@@ -5,6 +5,9 @@ import ctypes as C
 import os
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libplangen_hip.so")
+# Diagnostics superset (same object files + microbenchmarks / hazard screens / kernel-variant tables and the switches that make a handle
+# compute something else): loaded only by tools/, bench.py's instrumented pass and a few GPU tests -- never by the product path.
+DIAG_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libplangen_diag.so")
 
 PG_F32, PG_BF16, PG_I32, PG_I64 = 0, 1, 2, 3
 PG_MAX_VQ_LEVELS = 8
@@ -65,6 +68,31 @@ SYMBOLS = [
 ]
 
 _lib = None
+_diag = None
+
+
+def _bind(lib: C.CDLL) -> C.CDLL:
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)            # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load_diag() -> C.CDLL:
+    """Load libplangen_diag.so: every symbol of the product ABI (a handle created through it runs the product's own object code) plus
+    ``pg_diag_set_option`` and the ``pg_bench_*`` measurement entry points.  Measurement / test infrastructure only."""
+    global _diag
+    if _diag is not None:
+        return _diag
+    import torch  # noqa: F401  (same reason as in load())
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise RuntimeError(f"plangen_amd: diagnostics library not found at {DIAG_LIB_PATH}; build it with `make -C plangen_amd/csrc`.")
+    lib = _bind(C.CDLL(DIAG_LIB_PATH))
+    lib.pg_diag_set_option.restype = C.c_int
+    lib.pg_diag_set_option.argtypes = [_P, C.c_char_p, C.c_int64]
+    _diag = lib
+    return lib
 
 
 def load() -> C.CDLL:
@@ -81,10 +109,6 @@ def load() -> C.CDLL:
             f"plangen_amd: HIP library not found at {LIB_PATH}. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C plangen_amd/csrc`. "
             "There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
-    for name, res, args in SYMBOLS:
-        fn = getattr(lib, name)            # AttributeError if the symbol is not exported
-        fn.restype = res
-        fn.argtypes = args
+    lib = _bind(C.CDLL(LIB_PATH))
     _lib = lib
     return lib

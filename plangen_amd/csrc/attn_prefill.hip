@@ -360,8 +360,7 @@ void launch_attn_prefill_flash(hipStream_t s, const bf16* qbuf, bf16* obuf, cons
                                const int32_t* row_off, const int32_t* len, int R, int max_len, int nh, int slots, float scale) {
     if (R <= 0 || max_len <= 0) return;
     if (pg_tune->prefill_attn != 1) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_prefill_flash2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * FB_TILE); attr = true; }
+        (void)PG_DYN_LDS(attn_prefill_flash2_kernel, 4 * FB_TILE);
         const int nqt = (max_len + 127) / 128;
         hipLaunchKernelGGL(attn_prefill_flash2_kernel, dim3(nqt, nh, R), dim3(256), 4 * FB_TILE, s, qbuf, obuf, kc, vc, row_off, len, nh, slots, scale, nqt);
         return;
@@ -603,17 +602,14 @@ __global__ __launch_bounds__(64 * NW) void attn_vit_resident_kernel(const bf16* 
 void launch_attn_vit_flash(hipStream_t s, const bf16* qk, const bf16* vt, bf16* o, int B, int P, int C, int NH, float scale) {
     const long lds = (long)P * VA_ROW + 64L * (P * 2 + 16);
     if (pg_tune->vit_attn != 1 && lds <= 160 * 1024) {          // K / V^T of one head resident in LDS (vit_attn = 1 selects the 64-key tile kernel for A/B)
-        static bool attr = false;
         const int nw = pg_tune->vit_attn >= 4 ? pg_tune->vit_attn : 16;      // measured on MI355X (64 images): tower 41.8 / 36.7 / 35.5 / 34.9 ms at 4 / 8 / 12 / 16 waves, tile kernel 37.1
-        if (nw == 4) { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)attn_vit_resident_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a4 = true; }
-            hipLaunchKernelGGL(attn_vit_resident_kernel<4>, dim3(NH, B), dim3(256), (size_t)lds, s, qk, vt, o, P, C, scale); return; }
-        if (nw == 8) { static bool a8 = false; if (!a8) { (void)hipFuncSetAttribute((const void*)attn_vit_resident_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a8 = true; }
-            hipLaunchKernelGGL(attn_vit_resident_kernel<8>, dim3(NH, B), dim3(512), (size_t)lds, s, qk, vt, o, P, C, scale); return; }
-        if (nw == 16) { static bool a16 = false; if (!a16) { (void)hipFuncSetAttribute((const void*)attn_vit_resident_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); a16 = true; }
-            hipLaunchKernelGGL(attn_vit_resident_kernel<16>, dim3(NH, B), dim3(1024), (size_t)lds, s, qk, vt, o, P, C, scale); return; }
-        if (!attr) { (void)hipFuncSetAttribute((const void*)attn_vit_resident_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL(attn_vit_resident_kernel<12>, dim3(NH, B), dim3(768), (size_t)lds, s, qk, vt, o, P, C, scale);
-        return;
+        // ~154 KB of dynamic LDS: needs the per-device attribute; when it cannot be set (or the device offers less LDS) the tile kernel below runs
+#define VIT_RES(NW) if (PG_DYN_LDS(attn_vit_resident_kernel<NW>, 160 * 1024)) { hipLaunchKernelGGL(attn_vit_resident_kernel<NW>, dim3(NH, B), dim3(64 * NW), (size_t)lds, s, qk, vt, o, P, C, scale); return; }
+        if (nw == 4) { VIT_RES(4) }
+        else if (nw == 8) { VIT_RES(8) }
+        else if (nw == 12) { VIT_RES(12) }
+        else { VIT_RES(16) }
+#undef VIT_RES
     }
     hipLaunchKernelGGL(attn_vit_flash_kernel, dim3(P / 64, NH, B), dim3(256), 0, s, qk, vt, o, P, C, scale);
 }

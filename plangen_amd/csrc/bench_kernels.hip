@@ -9,6 +9,8 @@
 #include "../../include/plangen_hip.h"
 #include "kernels.h"
 #include "gemm_common.h"
+#include "diag.h"
+#include "gemm_skinny.h"      // g_sk4_prof, SK_BK
 
 __global__ void fill_bf16_kernel(bf16* p, long n, uint32_t seed) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -207,7 +209,6 @@ extern "C" int pg_bench_skinny_diag(int M, int N, int K, int variant, int S, int
 
 // Per-wave s_memtime stamps of ONE launch of a v4 variant (after warm-up launches on rotating weights):
 // stamps_host [nwaves][64] cycle counters; returns the number of waves, or < 0.
-extern unsigned long long* g_sk4_prof;
 extern "C" int pg_bench_sk4_profile(int M, int N, int K, int variant, int S, unsigned long long* stamps_host, int max_waves) {
     const long wbytes = (long)N * K * 2;
     const int nbuf = 8;
@@ -412,6 +413,97 @@ extern "C" int pg_bench_tr16_probe(const int* addr_host, unsigned short* out_hos
     hipMemcpy(out_host, o, 256 * 2, hipMemcpyDeviceToHost);
     hipFree(a); hipFree(o);
     return rc;
+}
+
+
+// ------------------------------------------------------------------------------- weight-stream kernel (round 4 run-ahead prefetcher; now only the background-load stressor)
+// One wave = one stream of 1 KiB wave-loads (16 B per lane, contiguous), DEPTH of them in flight, data discarded.  Trigger k of step st
+// (= the (first + k * stride)-th ticket of that step, i.e. the norm launch behind o_proj of layer k) releases layer k's list: gate|up,
+// down, the NEXT layer's qkv, in that order -- the order the main stream consumes them.  A piece index i of a matrix maps to
+// region i % R, piece i / R, so every consumer block's region gets its first pieces first.  Every spin is bounded (wall clock): a
+// prefetcher that sees no ticket for 30 ms exits; the main stream never waits for this kernel's data.
+template <int DEPTH, int NT, int REGS = 0>
+__global__ __launch_bounds__(128) void weight_prefetch_kernel(const PfLayer* __restrict__ plan, int n_layers, const uint32_t* prog, int steps,
+                                                              int per_step, int first, int stride, uint32_t* stats) {
+    __shared__ __attribute__((aligned(16))) char sink[2][1024];
+    const int lane = threadIdx.x & 63;
+    const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.x * (blockDim.x >> 6);
+    unsigned done_layers = 0, skipped = 0;
+    const long total = (long)steps * n_layers;
+    long k = 0;                                                 // global trigger index = st * n_layers + layer
+    unsigned long long t_last = wall_clock64();
+    while (k < total) {
+        const int st = (int)(k / n_layers), l = (int)(k % n_layers);
+        const unsigned target = (unsigned)st * per_step + first + l * stride;
+        unsigned p = 0;
+        if (per_step > 0)                                       // per_step == 0: free-running stressor (tools/sk4_load_stress.py), no tickets
+        for (;;) {                                              // relaxed poll by every lane of one load (a wave-uniform scalar would be cached)
+            p = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p >= target) break;
+            __builtin_amdgcn_s_sleep(16);
+            // no ticket for 30 ms (100 MHz clock): the loop is over or was aborted.  Before the FIRST ticket the bound is 2 ms: a first ticket that late
+            // means this kernel sits on the decode stream's own hardware queue and is what keeps the loop from starting -- leave at once
+            if (wall_clock64() - t_last > (k == 0 ? 200000ull : 3000000ull)) {
+                if (stats && threadIdx.x == 0 && blockIdx.x == 0) { stats[0] = done_layers; stats[1] = skipped; stats[2] = 1; }
+                return;
+            }
+        }
+        t_last = wall_clock64();
+        // lagging: when the main stream is already past LATER triggers, jump to the newest one (its weights are what is needed next)
+        if (per_step > 0) {
+            const unsigned into = p - (unsigned)st * per_step;                      // tickets of this step seen so far (may exceed per_step)
+            long knew = k;
+            if (into >= (unsigned)per_step) knew = (long)(st + into / per_step) * n_layers;       // at least one whole step ahead: restart at that step's layer 0 trigger
+            else if (into >= (unsigned)(first + stride)) { const int lmax = (int)((into - first) / stride); knew = (long)st * n_layers + (lmax < n_layers ? lmax : n_layers - 1); }
+            if (knew > k) { skipped += (unsigned)(knew - k); k = knew; continue; }
+        }
+        const PfLayer& L = plan[l];
+#pragma unroll 1
+        for (int mi = 0; mi < 4; ++mi) {
+            const char* base = (const char*)L.m[mi].base;
+            const unsigned npieces = L.m[mi].kib, R = L.m[mi].regions ? L.m[mi].regions : 1u;
+            if (!base) continue;
+            const unsigned per_region = npieces / R;                                 // pieces beyond R * per_region (none for the decode shapes) are left cold
+            unsigned i = wid;
+            const unsigned lim = per_region * R;
+            if constexpr (REGS) {       // stressor variant: plain register loads in groups of 8 (no LDS-DMA from this kernel)
+                for (; i < lim; i += nw * 8) {
+                    u32x4 t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned ii = i + u * nw < lim ? i + u * nw : i;
+                        const char* ptr = base + ((size_t)(ii % R) * per_region + ii / R) * 1024 + lane * 16;
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(t[u]) : "v"(ptr) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(t[u]));
+                }
+            } else
+            for (; i < lim; i += nw) {
+                const unsigned r = i % R, j = i / R;
+                const char* ptr = base + ((size_t)r * per_region + j) * 1024 + lane * 16;
+                // LDS-DMA into a 1 KiB per-wave sink nobody reads: no VGPR is written, so nothing the compiler re-uses can be overwritten by
+                // a load that lands later (a register-destination asm load whose result is "dead" gets its register recycled while in flight)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)ptr, (lds_ptr_t)sink[threadIdx.x >> 6], 16, 0, NT ? 2 : 0);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH - 1) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ++done_layers;
+        ++k;
+    }
+    if (stats && threadIdx.x == 0 && blockIdx.x == 0) { stats[0] = done_layers; stats[1] = skipped; stats[2] = 0; }
+}
+void launch_weight_prefetch(hipStream_t s, const PfLayer* plan_dev, int n_layers, const uint32_t* prog, int steps, int per_step,
+                            int first, int stride, int blocks, int depth, int nt, uint32_t* stats) {
+    if (steps <= 0 || n_layers <= 0) return;
+    dim3 g(blocks), b(128);
+#define PG_PF(D, N) hipLaunchKernelGGL((weight_prefetch_kernel<D, N>), g, b, 0, s, plan_dev, n_layers, prog, steps, per_step, first, stride, stats)
+    if (depth < 0) { hipLaunchKernelGGL((weight_prefetch_kernel<8, 0, 1>), g, b, 0, s, plan_dev, n_layers, prog, steps, per_step, first, stride, stats); return; }
+    if (nt) { if (depth >= 32) PG_PF(32, 1); else if (depth >= 16) PG_PF(16, 1); else PG_PF(8, 1); }
+    else { if (depth >= 32) PG_PF(32, 0); else if (depth >= 16) PG_PF(16, 0); else PG_PF(8, 0); }
+#undef PG_PF
 }
 
 

@@ -219,3 +219,21 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
 // the fused and the unfused prefill write identical bits (left to the compiler, `a*c - b*s` may contract either product)
 __device__ __forceinline__ float rope_lo(float x0, float x1, float c, float s) { return __builtin_fmaf(x0, c, -(x1 * s)); }   // out[j]    = x0 cos - x1 sin
 __device__ __forceinline__ float rope_hi(float x0, float x1, float c, float s) { return __builtin_fmaf(x1, c, x0 * s); }      // out[j+64] = x1 cos + x0 sin
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): set once per device the calling thread is on, result
+// checked (a process-wide "done" flag left a second GPU's handle launching without it).  One call site = one flag word, one bit
+// per device ordinal; evaluates to false when the attribute call fails (the caller falls back or lets the launch report the error).
+#define PG_DYN_LDS(kfn, bytes)                                                                                                  \
+    ([&]() -> bool {                                                                                                            \
+        static unsigned long long done_ = 0;                                                                                    \
+        int d_ = 0;                                                                                                             \
+        (void)hipGetDevice(&d_);                                                                                                \
+        const unsigned long long bit_ = 1ull << (d_ & 63);                                                                      \
+        if (done_ & bit_) return true;                                                                                          \
+        if (hipFuncSetAttribute((const void*)(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) {  \
+            (void)hipGetLastError();                                                                                            \
+            return false;                                                                                                       \
+        }                                                                                                                       \
+        done_ |= bit_;                                                                                                          \
+        return true;                                                                                                            \
+    }())

@@ -252,8 +252,7 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
 #define CH_LAUNCH(STAG, UP)                                                                                                  \
     {                                                                                                                         \
         auto kfn = conv3x3_halo_kernel<Epi<bf16>, STAG, UP>;                                                                  \
-        static bool attr = false;                                                                                             \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS); attr = true; } \
+        (void)PG_DYN_LDS(kfn, CH_LDS); \
         hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, H, Wd, gn_part);  \
     }
     if (gn_part && (e.ldc & 3) != 0) gn_part = nullptr;
@@ -349,8 +348,7 @@ bool conv_out_halo_try(hipStream_t s, const bf16* x, const bf16* w, const float*
     const int tiles = B * (H / CH_TH) * (Wd / CH_TW);
     if (tiles < 64) return false;
     auto kfn = conv3x3_out_halo_kernel;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_HALO_BYTES); attr = true; }
+    (void)PG_DYN_LDS(kfn, CH_HALO_BYTES);
     hipLaunchKernelGGL(kfn, dim3(tiles < 256 ? tiles : 256), dim3(512), CH_HALO_BYTES, s, x, w, bias, zeros, out, out_bf16, B, H, Wd, Cout);
     return true;
 }

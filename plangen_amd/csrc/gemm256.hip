@@ -42,12 +42,19 @@
 
 __device__ __forceinline__ void g2_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <class AL, class EP, int WM, int WN, bool ROPE = false>      // ROPE: the prefill QKV instantiation (RoPE + KV-write epilogue, act 3) -- its own kernel so its
+// MT1 (round 5): m-tiles of a wave's SECOND row half (4 = the 256-row tile; 3 / 2 = 224 / 192 rows per block at WM = 2).  The tile height is
+// picked per launch so that ceil(tiles / 256 CUs) x height is smallest: at the bench's packed prompt batch (13.4 k tokens) o_proj / down_proj are
+// 424 tiles of 256 rows = 1.66 rounds on 256 CUs (17 % of the launch idle) but 480 tiles of 224 rows = 1.875 rounds of 7/8 the work.  Only
+// the fragment reads and MFMAs of the second half shrink (phases 3 / 4: 4 x MT1 MFMAs... MT1 m-tiles x 2 n-tiles x 2 k-steps); the staging
+// stream, its counted waits and the LDS layout are unchanged (the half-tile HA1 still brings 64 rows per wave row, 64 - 16 MT1 of them unused).
+template <class AL, class EP, int WM, int WN, bool ROPE = false, int MT1 = 4>      // ROPE: the prefill QKV instantiation (RoPE + KV-write epilogue, act 3) -- its own kernel so its
 __global__ __launch_bounds__(512) void gemm256_kernel(                 // register needs do not reach the other users of this template
 AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                                                      long strideA2, long strideB2, EP ep, int M, int N, int K, int ntm, int ntn) {
     static_assert(WM * WN == 8 && (WN == 2 || WN == 4), "eight waves, 128x64 of C each");
-    constexpr int BM = WM * 128, BN = WN * 64;
+    static_assert(MT1 >= 1 && MT1 <= 4, "second row half: 1..4 m-tiles");
+    constexpr int WROWS = 64 + 16 * MT1, NMT = 4 + MT1;          // rows / m-tiles of C per wave row
+    constexpr int BM = WM * WROWS, BN = WN * 64;
     constexpr int AH = WM * 64 * 128, BH = WN * 32 * 128;        // bytes per A / W half-tile
     constexpr int BUF = 2 * AH + 2 * BH;                         // one K tile: [HA0 | HA1 | HB0 | HB1]
     constexpr int NA = WM, NB = WN / 2;                          // global_load_lds per thread per half-tile
@@ -92,7 +99,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int r = i * 64 + srow;                     // LDS row of the half-tile -> (wave row r>>6, row r&63)
-                al.init(h * NA + i, m0 + (r >> 6) * 128 + h * 64 + (r & 63));
+                al.init(h * NA + i, m0 + (r >> 6) * WROWS + h * 64 + (r & 63));   // (MT1 < 4: rows 16 MT1 .. 63 of HA1 are staged but never read)
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
@@ -122,7 +129,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
     constexpr std::integral_constant<int, 0> H0{}; constexpr std::integral_constant<int, 1> H1{};
     auto prologue = [&]() __attribute__((always_inline)) { stage_A(H0, 0); stage_B(H0, 0); stage_B(H1, 0); stage_A(H1, 0); stage_A(H0, 1); stage_B(H0, 1); };
 
-    f32x4 acc[8][4];
+    f32x4 acc[NMT][4];
     bf16x8 a[4][2], b0[2][2], b1[2][2];
 
     // counted wait: the four half-tiles issued after the one needed next = 2 A + 2 W halves
@@ -137,7 +144,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                          \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                    \
+        _Pragma("unroll") for (int mt = 0; mt < (MH ? MT1 : 4); ++mt)                                       \
             _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                \
                 acc[MH * 4 + mt][NH * 2 + nt] =                                                             \
                     __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[nt][ks], a[mt][ks], acc[MH * 4 + mt][NH * 2 + nt], 0, 0, 0); \
@@ -149,7 +156,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
     if (have) prologue();
     for (int base = 0; have; ) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NMT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         G2_WAIT()
@@ -185,7 +192,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
             G2_MFMA_SECTION(0, b1, 1)
             // ---- phase 3: quadrant (1,1): fragments of HA1; stage HA0(kt+2)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT1; ++mt) {
                 a[mt][0] = *(const bf16x8*)(buf + AH + aoff0 + mt * 2048);
                 a[mt][1] = *(const bf16x8*)(buf + AH + aoff1 + mt * 2048);
             }
@@ -202,7 +209,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
         // every wave is past its last ds_read: the next tile's first loads go out before this tile's
         // stores (same vmcnt counter, but loads return in order among themselves and the clamped tail
         // stages of this tile were issued earlier by the same wave to the same LDS bytes)
-        const int em0 = m0 + wr * 128 + lr, en0 = n0 + wc * 64 + g * 4, ecol0 = n0 + wc * 64;   // setup() below moves m0 / n0 on
+        const int em0 = m0 + wr * WROWS + lr, en0 = n0 + wc * 64 + g * 4, ecol0 = n0 + wc * 64;   // setup() below moves m0 / n0 on
         base += G;
         have = base < NT && setup(base);
         if (have) prologue();
@@ -216,14 +223,14 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
             const int HDm = R.nh * 128;
             // per-row metadata of the lane's 8 rows first (two dependent round trips for all of them); the cos / sin rows of m-tile mt+1 are
             // requested under the stores of m-tile mt (single-buffered: the accumulators leave ~60 VGPRs, a double buffer spilled)
-            int rowv[8], slotv[8], posv[8];
+            int rowv[NMT], slotv[NMT], posv[NMT];
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
                 const int m = em0 + mt * 16, mc = m < M ? m : M - 1;
                 rowv[mt] = R.tok_row[mc]; slotv[mt] = R.tok_j[mc];
             }
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
                 const int pos = R.pos_off[rowv[mt]] + slotv[mt];
                 posv[mt] = pos < R.max_pos ? pos : R.max_pos - 1;
             }
@@ -246,7 +253,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
             };
             fetch(0);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
                 const int m = em0 + mt * 16, row = rowv[mt], slot = slotv[mt];
                 const bool ok = m < M && slot < R.slots;
                 uint2 q[4];
@@ -263,7 +270,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                     }
                     q[nt].x = pack_bf16x2(o[0], o[1]); q[nt].y = pack_bf16x2(o[2], o[3]);
                 }
-                if (mt + 1 < 8) fetch(mt + 1);                                  // in flight under this m-tile's stores
+                if (mt + 1 < NMT) fetch(mt + 1);                                  // in flight under this m-tile's stores
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const int sec = secv[nt], head = headv[nt], t = tv[nt];
@@ -282,7 +289,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
             // at column n/2 -- the fp32 gate|up tensor is never written.  out: bf16 [M, N/2], ldc = N/2.
             bf16* hout = (bf16*)ep.e.out + coff;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
+            for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const f32x4 v = acc[mt][nt];
@@ -301,11 +308,17 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
         } else {
             // two m-tile rows (8 fragments) per batch: their bias / residual loads go out together (gemm_common.h store4_batch)
 #pragma unroll
-            for (int mp = 0; mp < 4; ++mp) {
+            for (int mp = 0; mp < NMT / 2; ++mp) {
                 int rows[8], cols[8]; f32x4 av[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { rows[i] = em0 + (mp * 2 + (i >> 2)) * 16; cols[i] = en0 + (i & 3) * 16; av[i] = acc[mp * 2 + (i >> 2)][i & 3]; }
                 ep.template store4_batch<8>(coff, roff, rows, cols, av, vec);
+            }
+            if constexpr (NMT & 1) {                              // odd tile heights: the last m-tile row on its own
+                int rows[4], cols[4]; f32x4 av[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { rows[i] = em0 + (NMT - 1) * 16; cols[i] = en0 + i * 16; av[i] = acc[NMT - 1][i]; }
+                ep.template store4_batch<4>(coff, roff, rows, cols, av, vec);
             }
         }
     }
@@ -315,17 +328,32 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
 }
 
 
-template <class AL, int WM, int WN, bool ROPE = false>
+template <class AL, int WM, int WN, bool ROPE = false, int MT1 = 4>
 static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long strideA, long strideB, long strideA2, long strideB2,
                       const Epi<bf16>& ep, int M, int N, int K, int batch, int batch2) {
-    constexpr int BM = WM * 128, BN = WN * 64, LDS = 2 * (2 * WM * 64 * 128 + 2 * WN * 32 * 128);
+    constexpr int BM = WM * (64 + 16 * MT1), BN = WN * 64, LDS = 2 * (2 * WM * 64 * 128 + 2 * WN * 32 * 128);
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int per_batch = 256 / (batch * batch2) > 8 ? 256 / (batch * batch2) : 8;   // blocks per (batch) slice: one per CU overall
     dim3 grid(ntm * ntn < per_batch ? ntm * ntn : per_batch, batch, batch2), block(512);
-    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN, ROPE>;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN, ROPE, MT1>;
+    (void)PG_DYN_LDS(kfn, LDS);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
+}
+
+// Tile height of a plain-A launch (round 5): rounds of 256 resident blocks x rows per tile (+ a fixed per-tile share for the epilogue
+// and the pipeline fill, in row equivalents), smallest wins; ties keep the taller tile.  Returns MT1 (4 / 3 / 2 = 256 / 224 / 192 rows).
+static int pick_tile_height(int M, int N, int batches) {
+    if (pg_tune->gemm256 >= 4) return pg_tune->gemm256 == 4 ? 4 : pg_tune->gemm256 == 5 ? 3 : 2;      // A/B: 4 / 5 / 6 pin 256 / 224 / 192 rows
+    if (batches != 1) return 4;
+    const int ntn = (N + 255) / 256;
+    int best = 4; long best_cost = -1;
+    for (int mt1 = 4; mt1 >= 2; --mt1) {
+        const int bm = 2 * (64 + 16 * mt1);
+        const long tiles = (long)((M + bm - 1) / bm) * ntn;
+        const long cost = ((tiles + 255) / 256) * (bm + 16);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mt1; }
+    }
+    return best;
 }
 
 // Takes the shapes the big tiles fill well; everything else stays on the 128^2 kernel.
@@ -343,8 +371,11 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
     Epi<bf16> ep{e, M, N};
     if (a.kind == 0) {
         PlainLoaderB<bf16> al; al.A = (const bf16*)a.ptr; al.lda = a.lda; al.M = M;
-        if (e.act == 3) launch256<PlainLoaderB<bf16>, 2, 4, true>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
-        else launch256<PlainLoaderB<bf16>, 2, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+        const int mt1 = pick_tile_height(M, N, batch * batch2);
+#define G2_LAUNCH(ROPE_, MT1_) launch256<PlainLoaderB<bf16>, 2, 4, ROPE_, MT1_>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2)
+        if (e.act == 3) { if (mt1 == 3) G2_LAUNCH(true, 3); else if (mt1 == 2) G2_LAUNCH(true, 2); else G2_LAUNCH(true, 4); }
+        else { if (mt1 == 3) G2_LAUNCH(false, 3); else if (mt1 == 2) G2_LAUNCH(false, 2); else G2_LAUNCH(false, 4); }
+#undef G2_LAUNCH
         return true;
     }
     if (e.act == 3) return false;

@@ -1,0 +1,555 @@
+// Skinny (decode) weight-streaming GEMM kernel templates v1 / v3 / v4 and their launch templates: included by gemm.hip, which instantiates
+// the PRODUCTION dispatch only, and by diag_gemm.hip (libplangen_diag.so: sweep / ablation / hazard-forensics instantiations).
+#pragma once
+#include "kernels.h"
+#include "gemm_common.h"
+
+// ------------------------------------------------------------------------------- skinny GEMM
+#define SK_BK 128
+#define SK_ROWB 288           // LDS row stride (256 B of k + 32 B pad: conflict-free ds_read_b128 for the (lr, g) fragment order)
+
+
+// Block epilogue of the skinny kernels: the NW waves' accumulators (MFMA C layout: lane holds
+// 4 rows x 1 column) are transposed through LDS so every lane stores 16 contiguous bytes
+// instead of 32 scattered dword stores.  smem must hold MT*16 rows x (NW*16+4) floats.
+template <int MT, int NW>
+__device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)[MT], float* __restrict__ o, int M, int N,
+                                                  int mbase, int nbase, int w, int g, int lr, int tid, int wt = 0) {
+    constexpr int LD = NW * 16 + 4, NTH = NW * 64, V4 = NW * 4;        // float4 per tile row
+    float* t = (float*)smem;
+    __syncthreads();                                   // every wave is done reading the x tiles
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[(mt * 16 + g * 4 + r) * LD + w * 16 + lr] = acc[mt][r];
+    __syncthreads();
+    for (int v = tid; v < MT * 16 * V4; v += NTH) {
+        const int row = v / V4, c4 = (v % V4) * 4;
+        const int m = mbase + row, n = nbase + c4;
+        if (m < M && n < N) {
+            const f32x4 v4 = *(const f32x4*)(t + row * LD + c4);
+            float* p = o + (long)m * N + n;
+            // wt: write-through (sc1) -- the slab leaves this XCD's L2 while the kernel runs, not as dirty lines at the boundary
+            // `s_nop 1` INSIDE the statement: hipcc does not know this is a 128-bit VMEM store, so it neither keeps the data registers
+            // alive nor pads the store-data hazard (a VALU write to them needs 2 wait states); see sk4_store_direct
+            if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v4) : "memory");
+            else __builtin_nontemporal_store(v4, (f32x4*)p);
+        }
+    }
+}
+
+// SwiGLU epilogue (S == 1 only): every 16-column n-tile is [8 gate | 8 up] (weights interleaved
+// in blocks of 8 at load time), so h = silu(g) * u for 8 output columns per tile comes straight
+// out of the transposed LDS tile; bf16 h [M, I] is written, no fp32 slab, no extra kernel.
+template <int MT, int NW>
+__device__ __forceinline__ void skinny_store_swiglu(char* smem, const f32x4 (&acc)[MT], bf16* __restrict__ h, int M, int I,
+                                                    int mbase, int nblk, int w, int g, int lr, int tid) {
+    constexpr int LD = NW * 16 + 4, NTH = NW * 64, OC = NW * 8;        // outputs per tile row
+    float* t = (float*)smem;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[(mt * 16 + g * 4 + r) * LD + w * 16 + lr] = acc[mt][r];
+    __syncthreads();
+    for (int v = tid; v < MT * 16 * (OC / 2); v += NTH) {
+        const int row = v / (OC / 2), c2 = (v % (OC / 2)) * 2;          // c2 in [0, OC), even
+        const int m = mbase + row, col = nblk * OC + c2;
+        if (m < M && col < I) {
+            const int tc = (c2 >> 3) * 16 + (c2 & 7);                   // gate column in the tile
+            const float g0 = t[row * LD + tc], g1 = t[row * LD + tc + 1];
+            const float u0 = t[row * LD + tc + 8], u1 = t[row * LD + tc + 9];
+            const float h0 = (g0 / (1.f + expf(-g0))) * u0, h1 = (g1 / (1.f + expf(-g1))) * u1;
+            *(uint32_t*)(h + (long)m * I + col) = pack_bf16x2(h0, h1);
+        }
+    }
+}
+
+// MFMA phase of one 128-wide K chunk: A fragments (x tile in LDS, row stride SK_ROWB) are read
+// one m-tile PAIR ahead of the MFMAs that consume them (double-buffered registers), and the
+// two m-tiles of a pair alternate accumulators so no MFMA waits on the previous one's result.
+// Without this hipcc serialises ds_read -> s_waitcnt lgkmcnt(0) -> mfma through one fragment
+// register (measured ~80 clk per MFMA per SIMD instead of ~17).
+template <int MT>
+__device__ __forceinline__ void skinny_mfma_chunk(const char* xt, int lr, int g, const bf16x8 (&wc)[4], f32x4 (&acc)[MT]) {
+    const char* rp = xt + lr * SK_ROWB + g * 16;
+    if constexpr (MT == 1) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(rp + i * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], wc[i], acc[0], 0, 0, 0);
+    } else {
+        constexpr int NP = MT / 2;
+        bf16x8 af[2][2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[0][h][i] = *(const bf16x8*)(rp + h * 16 * SK_ROWB + i * 64);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p + 1 < NP) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        af[(p + 1) & 1][h][i] = *(const bf16x8*)(rp + ((p + 1) * 2 + h) * 16 * SK_ROWB + i * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the next pair's 8 reads ahead of this pair's MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p & 1][0][i], wc[i], acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[p & 1][1][i], wc[i], acc[2 * p + 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+                                                         float* __restrict__ out, int M, int N, int K, int nck) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // 2 * MT*16*SK_ROWB
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
+    const int split = blockIdx.y, mblk = blockIdx.z;
+    const int mbase = mblk * 128;
+    const int n = blockIdx.x * 64 + w * 16 + lr;
+    // fragment order: k-step i, lane (lr, g) holds k = i*32 + g*8 .. +8, so the 4 lanes of a W row
+    // read one full 64-byte sector per load instruction
+    const bf16* wp = W + (long)(n < N ? n : N - 1) * K + g * 8;
+    const int kbeg = split * nck * SK_BK;
+    constexpr int XB = MT * 16 * SK_ROWB;
+
+    u32x4 xs[MT];                     // staging registers for the x tile: MT x 16 B per thread
+    auto xload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + j * 256, row = v >> 4, cv = v & 15;
+            const int m = mbase + row;
+            if (m < M) xs[j] = *(const u32x4*)(x + (long)m * K + k0 + cv * 8);
+            else xs[j] = (u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto xstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + j * 256, row = v >> 4, cv = v & 15;
+            *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
+        }
+    };
+    bf16x8 wc[4], wn[4];
+    auto wload = [&](bf16x8* dst, int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(wp + k0 + i * 32);
+    };
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    wload(wc, kbeg);
+    xload(kbeg);
+    xstore(0);
+    __syncthreads();
+    for (int c = 0; c < nck; ++c) {
+        const int knext = kbeg + (c + 1) * SK_BK;
+        const bool more = c + 1 < nck;
+        if (more) { wload(wn, knext); xload(knext); }
+        const char* xt = smem + (c & 1) * XB;
+        skinny_mfma_chunk<MT>(xt, lr, g, wc, acc);
+        if (more) {
+            xstore((c + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wc[i] = wn[i];
+        }
+        __syncthreads();
+    }
+    skinny_store_tile<MT, 4>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid);
+}
+
+// ------------------------------------------------------------------------------- skinny GEMM v3
+// Same geometry as v1 (BN = 64: 4 waves x 16 columns, BK = 128) but the W stream is decoupled
+// from the per-chunk barrier: a register ring of depth D keeps D chunks of every wave's W
+// rows in flight (the HBM requests of chunk c+D are issued while chunk c computes), the chunk
+// loop is fully unrolled (NCK = chunks per block, compile time) so the ring is statically
+// indexed.  XDB: x tile double-buffered (2 blocks/CU at MT=8) or single-buffered (4 blocks/CU).
+template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+                                                               float* __restrict__ out, int M, int N, int K, int wt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XB = MT * 16 * SK_ROWB, NTH = 64 * NW, BN = 16 * NW;
+    constexpr int XV = (MT * 256 + NTH - 1) / NTH;                     // x vectors per thread per chunk
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
+    const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
+    const int bx = blockIdx.x;
+    const int n = bx * BN + w * 16 + lr;
+    const int kbeg = split * NCK * SK_BK;
+    // Row-major W: lane (lr, g) reads W[n][k + i*32 + g*8 ..+8].  TILED W (decode copy, built at load
+    // time): [n-tile][k-chunk][i][lane][8] -- every wave load instruction is one contiguous 1 KiB and
+    // an n-tile's whole K stream is contiguous in HBM (DRAM-page friendly).
+    const int ntile = bx * NW + w, ntiles = (N + 15) / 16;
+    const bf16* wp = TILED ? W + ((long)(ntile < ntiles ? ntile : ntiles - 1) * (K / SK_BK) + split * NCK) * 2048 + l * 8
+                           : W + (long)(n < N ? n : N - 1) * K + kbeg + g * 8;
+    constexpr int WCH = TILED ? 2048 : SK_BK, WI = TILED ? 512 : 32;       // element strides per chunk / per k-step
+    const bf16* xp = x + kbeg;
+
+    u32x4 xs[XV];
+    auto xload = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < XV; ++j) {
+            const int v = tid + j * NTH, row = v >> 4, cv = v & 15;
+            const int m = mbase + row;
+            // BRANCH-FREE (row clamped into the matrix; rows >= M are never stored): behind `if (m < M)` hipcc put every x load
+            // in its own exec-masked block with `s_waitcnt vmcnt(0)` at the joins -- four serialised memory round trips (and a drain
+            // of the W ring's first loads) before the first MFMA
+            if constexpr ((MT * 256) % NTH == 0) {
+                xs[j] = *(const u32x4*)(xp + (long)(m < M ? m : M - 1) * K + c * SK_BK + cv * 8);
+            } else {
+                if (row < MT * 16) xs[j] = *(const u32x4*)(xp + (long)(m < M ? m : M - 1) * K + c * SK_BK + cv * 8);
+                else xs[j] = (u32x4){0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    auto xstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < XV; ++j) {
+            const int v = tid + j * NTH, row = v >> 4, cv = v & 15;
+            // unconditional when the tile divides over the block (hipcc cannot prove tid < NTH, keeps the guard, and SINKS the matching
+            // x load into it: a conditional load with a `vmcnt(0)` at the join)
+            if ((MT * 256) % NTH == 0 || row < MT * 16) *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
+        }
+    };
+    bf16x8 wr[D][4];
+#pragma unroll
+    for (int c = 0; c < D && c < NCK; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wr[c][i] = *(const bf16x8*)(wp + c * WCH + i * WI);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    xload(0);
+    xstore(0);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) {
+        if (c + 1 < NCK) xload(c + 1);
+        const char* xt = smem + (XDB ? (c & 1) * XB : 0);
+        skinny_mfma_chunk<MT>(xt, lr, g, wr[c % D], acc);
+        if (c + D < NCK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wr[c % D][i] = *(const bf16x8*)(wp + (c + D) * WCH + i * WI);
+        }
+        if (c + 1 < NCK) {
+            if (!XDB) __syncthreads();
+            xstore(XDB ? ((c + 1) & 1) : 0);
+            __syncthreads();
+        }
+    }
+    if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, bx, w, g, lr, tid);
+    else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, bx * BN, w, g, lr, tid, wt);
+}
+template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false>
+static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+    constexpr int XL = (XDB ? 2 : 1) * MT * 16 * SK_ROWB, TL = MT * 16 * (NW * 16 + 4) * 4;
+    constexpr int LDS = XL > TL ? XL : TL;
+    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED>;
+    (void)PG_DYN_LDS(kfn, LDS);
+    dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K, pg_tune->wt_store & 1);
+}
+template <int D, bool XDB>
+static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
+    const int nck = K / SK_BK / S;
+    if (nck * S * SK_BK != K) return 0;
+    switch (nck) {
+        case 1: launch_sk3<8, 1, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 2: launch_sk3<8, 2, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 4: launch_sk3<8, 4, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 8: launch_sk3<8, 8, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 11: launch_sk3<8, 11, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 16: launch_sk3<8, 16, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        case 22: launch_sk3<8, 22, D, XDB>(s, x, W, out, M, N, K, S); return 1;
+        default: return 0;
+    }
+}
+
+
+// ---- production dispatch: v3 (W register ring depth 2, double-buffered x tile) ----
+template <int MT, int EPI, int NW = 4, bool TILED = false, int D = 2>
+static bool sk3_prod_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck) {
+    switch (nck) {
+        case 1: launch_sk3<MT, 1, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 2: launch_sk3<MT, 2, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 4: launch_sk3<MT, 4, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 8: launch_sk3<MT, 8, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 11: launch_sk3<MT, 11, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 16: launch_sk3<MT, 16, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 22: launch_sk3<MT, 22, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        default: return false;
+    }
+}
+// ------------------------------------------------------------------------------- skinny GEMM v4 ("stream")
+// Same block tile as v3 (BN = 16*NW columns, MT*16 rows, BK = 128, tiled W, W register ring of depth WD) but
+// the x tile never touches a VGPR: every 128-wide K chunk of the block's MT*16 rows is brought HBM/L2 -> LDS by
+// LDS-DMA (global_load_lds, 1 KiB per wave instruction) into a ring of XD chunk slots, XD-1 chunks AHEAD of
+// the MFMAs that read it.  v3 staged x through registers one chunk ahead: a block's every chunk then waited
+// for an L2 round trip (measured: x-tile loads = 3.6 of the qkv kernel's 15 us); here that latency sits under
+// XD-1 chunks of MFMA + W streaming, the xstore LDS writes and their staging registers are gone, and there is
+// ONE s_barrier per chunk (no vmcnt(0)/lgkmcnt(0) drain: raw s_barrier + counted vmcnt).
+//   LDS chunk slot: MT*16 rows x 256 B, no padding (the DMA writes 64 consecutive 16-byte slots per
+//   instruction = 4 rows); bank conflicts are avoided by permuting the SOURCE: slot s of row r holds logical
+//   16-byte chunk s ^ (r & 15), so the fragment read of lane (lr, g), k-step i is at
+//   row*256 + (((4i + g) ^ lr) << 4): 16 distinct slots per 16-lane group.
+//   Program order of VMEM ops per wave (all counted by hand, W loads by the compiler):
+//     prologue  X(0) .. X(XD-2), W(0) .. W(WD-1)
+//     chunk c   s_waitcnt vmcnt(A(c))  -> this wave's X(c) pieces have landed        (A = ops issued after X(c))
+//               s_barrier              -> every wave's X(c) pieces have landed, every wave is done reading X(c-1)
+//               issue X(c+XD-1) into the slot of X(c-1)
+//               MFMA on X(c), W(c)     (the compiler waits for W(c))
+//               issue W(c+WD) into W(c)'s registers
+constexpr int sk4_wait_count(int c, int NCK, int XD, int WD, int MT, int ahead = 0) {      // ahead = 1: chunk c+1 (not only c) retired at chunk c's barrier
+    int ops = 0, lastX[64] = {};
+    for (int p = 0; p < XD - 1 && p < NCK; ++p) { ops += MT; lastX[p] = ops; }
+    for (int p = 0; p < WD && p < NCK; ++p) ops += 4;
+    for (int it = 0; it < NCK; ++it) {
+        if (it == c) return ops - lastX[(c + ahead < NCK) ? c + ahead : NCK - 1];
+        if (it + XD - 1 < NCK) { ops += MT; lastX[it + XD - 1] = ops; }
+        if (it + WD < NCK) ops += 4;
+    }
+    return 0;
+}
+// ops issued after W(c)'s last load at the point of chunk c where the MFMAs start (after X(c+XD-1) was issued)
+constexpr int sk4_wait_count_w(int c, int NCK, int XD, int WD, int MT) {
+    int ops = 0, lastW[64] = {};
+    for (int p = 0; p < XD - 1 && p < NCK; ++p) ops += MT;
+    for (int p = 0; p < WD && p < NCK; ++p) { ops += 4; lastW[p] = ops; }
+    for (int it = 0; it < NCK; ++it) {
+        if (it + XD - 1 < NCK) ops += MT;
+        if (it == c) return ops - lastW[c];
+        if (it + WD < NCK) { ops += 4; lastW[it + WD] = ops; }
+    }
+    return 0;
+}
+// W fragment load as OPAQUE asm: the compiler may schedule a plain load from a const __restrict__ pointer across an
+// `asm volatile("" ::: "memory")` fence (nothing can alias it), which silently changes the VMEM issue order the hand-counted vmcnt
+// waits of the v4 kernel assume.  asm volatile statements keep their program order, so the simulated order of sk4_wait_count() is the
+// order in the instruction stream.  (Round 2 attributed a "stale 4-row x piece on a cold first launch" to this; round 4 found that symptom's
+// real cause in the epilogue's asm store, see sk4_store_direct.  The ordering argument stands on its own.)
+__device__ __forceinline__ void sk4_wload(bf16x8& dst, const bf16* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(p) : "memory");
+}
+// wait until at most N_ VMEM ops are outstanding; the W registers are in/out operands so no consumer of them can be scheduled above
+template <int N_> __device__ __forceinline__ void wait_vmcnt_w(bf16x8 (&wv)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]) : "n"(N_ > 63 ? 63 : N_) : "memory");
+}
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_ > 63 ? 63 : N_) : "memory"); }   // 6-bit field: clamping only waits longer
+
+template <bool SWAP>
+__device__ __forceinline__ f32x4 sk4_mfma(const bf16x8& a, const bf16x8& wv, const f32x4& c) {
+    // SWAP: D = W . x^T -- the lane then holds 4 consecutive output COLUMNS of one row (16-byte epilogue stores)
+    if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, a, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, wv, c, 0, 0, 0);
+}
+template <int MT, bool SWAP = false, int ROWX = 0, bool ROT = false>
+__device__ __forceinline__ void sk4_mfma_chunk(const char* xt, int lr, int g, const bf16x8 (&wc)[4], f32x4 (&acc)[MT]) {
+    // A fragment (m-tile mt, k-step i): row mt*16 + lr, logical 16-byte chunk 4i + g, swizzled by lr
+    const char* rp = xt + (lr ^ ROWX) * 256;
+    int so[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) so[i] = (ROT ? ((i * 4 + g + lr) & 15) : ((i * 4 + g) ^ lr)) << 4;
+    if constexpr (MT == 1) {
+        bf16x8 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(rp + so[i]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[0] = sk4_mfma<SWAP>(a[i], wc[i], acc[0]);
+        __builtin_amdgcn_sched_barrier(0);      // the ds_reads / MFMAs of a chunk stay between its barrier and the next one (the DMA that re-stages the slot follows that barrier)
+    } else {
+        constexpr int NP = MT / 2;
+        bf16x8 af[2][2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[0][h][i] = *(const bf16x8*)(rp + h * 4096 + so[i]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p + 1 < NP) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        af[(p + 1) & 1][h][i] = *(const bf16x8*)(rp + ((p + 1) * 2 + h) * 4096 + so[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * p] = sk4_mfma<SWAP>(af[p & 1][0][i], wc[i], acc[2 * p]);
+                acc[2 * p + 1] = sk4_mfma<SWAP>(af[p & 1][1][i], wc[i], acc[2 * p + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+// Epilogues for the swapped accumulator layout: lane (lr, g) holds out[row mt*16 + lr][n-tile column 4g .. 4g+3].
+// WT: write-through (sc1) stores -- the slab leaves the XCD's L2 while the kernel still runs instead of as dirty lines
+// at the kernel boundary (the boundary pays ~0.2-0.4 us per dirty MB).
+template <int MT, bool WT = false>
+__device__ __forceinline__ void sk4_store_direct(const f32x4 (&acc)[MT], float* __restrict__ o, int M, int N, int mbase, int ncol0, int g, int lr) {
+    const int n = ncol0 + g * 4;
+    if (n >= N) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mbase + mt * 16 + lr;
+        if (m < M) {
+            float* p = o + (long)m * N + n;
+            // ROOT CAUSE of the "stale x piece" failures of rounds 2-3 (found in round 4 by running the kernel under a concurrent memory
+            // load, tools/sk4_load_stress.py): this statement used to be the bare store.  hipcc treats an asm statement as opaque -- it does
+            // not know a 128-bit VMEM store reads its data registers for two more issue slots -- and re-used acc[mt]'s first register for the
+            // NEXT m-tile's row index one instruction later (`v_or_b32 v12, 16, v18` behind `global_store_dwordx4 .., v[12:15]`).  When the
+            // memory pipeline is back-pressured (cold launch, another stream streaming) the store then wrote the clobbered dword for the
+            // lanes it reads last: rows 12-15 of every m-tile except the block's last one (whose store is followed by s_endpgm) lost a
+            // whole split's contribution -- exactly the "rows 12-15 / 28-31 / 44-47" signature that was blamed on the LDS-DMA staging.
+            // With accumulators in AGPRs (another register budget) the data goes through fresh VGPRs and the fault disappears, which is
+            // how it was isolated.  Fix = the ISA's required wait states inside the statement (CDNA guide 5.7: an asm store_dwordx3/x4
+            // ends with `s_nop 1`).
+            if constexpr (WT) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(acc[mt]) : "memory");
+            else __builtin_nontemporal_store(acc[mt], (f32x4*)p);
+        }
+    }
+}
+// SwiGLU: an n-tile is [8 gate | 8 up]: lanes g = 0,1 hold gate columns 4g..4g+3, lanes g + 2 the matching up columns
+template <int MT>
+__device__ __forceinline__ void sk4_store_swiglu_direct(const f32x4 (&acc)[MT], bf16* __restrict__ h, int M, int I, int mbase, int ntile, int g, int lr) {
+    const int col = ntile * 8 + (g & 1) * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = __shfl_xor(acc[mt][r], 32, 64);
+        const int m = mbase + mt * 16 + lr;
+        if (g < 2 && m < M && col < I) {
+            float hv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float gt = acc[mt][r]; hv[r] = (gt / (1.f + expf(-gt))) * u[r]; }
+            u32x2 pk; pk.x = pack_bf16x2(hv[0], hv[1]); pk.y = pack_bf16x2(hv[2], hv[3]);
+            *(u32x2*)(h + (long)m * I + col) = pk;
+        }
+    }
+}
+
+template <int C, int NCK, int XD, int WD, int MT, class F> __device__ __forceinline__ void sk4_static_for(F&& f) {
+    if constexpr (C < NCK) { f(std::integral_constant<int, C>{}); sk4_static_for<C + 1, NCK, XD, WD, MT>(f); }
+}
+
+// MS = 2: 8 waves per block, wave w = (n-tile w & 3, row half w >> 2): two waves per SIMD, so one wave's LDS fragment
+// reads run under the other's MFMAs (measured with 4 lock-stepped waves: reads and MFMAs of a chunk serialise,
+// ~1050 cycles per chunk instead of ~550).  Both row halves load the same W fragments (second one hits L1/L2).
+template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>      // ABL (bench only): 1 no x DMA / barriers, 2 no MFMA, 4 no stores, 32 per-wave s_memtime stamps
+__global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
+                                                               float* __restrict__ out, int M, int N, int K, unsigned long long* prof) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MTW = MT / MS;                                     // m-tiles per wave
+    // tuning aid: per-wave s_memtime stamps (prof != nullptr only from the microbenchmark): 64 slots per wave
+    constexpr bool PROF = (ABL & 32) != 0;
+    int pslot = 0;
+    unsigned long long* pw = (PROF && prof) ? prof + ((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (4 * MS) + (threadIdx.x >> 6)) * 64 : nullptr;
+    auto stamp = [&]() { if constexpr (PROF) { if (pw && (threadIdx.x & 63) == 0 && pslot < 64) pw[pslot] = __builtin_readcyclecounter(); ++pslot; } };
+    stamp();
+    constexpr int XB = MT * 16 * 256;                                // bytes per x chunk slot
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, lr = l & 15;
+    const int wn = w & 3, wm = w >> 2;
+    const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
+    const int ntile = blockIdx.x * 4 + wn, ntiles = (N + 15) / 16;
+    const bf16* wp = W + ((long)(ntile < ntiles ? ntile : ntiles - 1) * (K / SK_BK) + split * NCK) * 2048 + l * 8;
+    // x DMA: wave w owns pieces w*MTW .. w*MTW+MTW-1 of every chunk; piece q = rows 4q .. 4q+3
+    const bf16* xsrc[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+        const int r = ((ABL & 1024) ? (j * 4 + w) : (w * MTW + j)) * 4 + (l >> 4);       // ABL 1024 (hazard screen): wave w owns pieces w, w+4, w+8, ... (one per 4 KiB LDS page)
+        const int m = mbase + r;
+        // ABL 4096 (hazard screen): rotation swizzle -- LDS position p of row r holds logical chunk (p - r) & 15 -- instead of the XOR swizzle
+        xsrc[j] = x + (long)(m < M ? m : M - 1) * K + split * NCK * SK_BK + (((ABL & 4096) ? (((l & 15) - (r & 15)) & 15) : ((l & 15) ^ (r & 15))) << 3);
+    }
+    auto issueX = [&](int c) {
+        char* slot = smem + (c % XD) * XB + w * (MTW * 1024);
+#pragma unroll
+        for (int jj = 0; jj < MTW; ++jj) {
+            const int j = (ABL & 128) ? MTW - 1 - jj : jj;                       // ABL 128 (hazard screen): pieces issued in reverse order
+            if constexpr (ABL & 1024) glds16(xsrc[j] + c * SK_BK, smem + (c % XD) * XB + (j * 4 + w) * 1024);
+            else if constexpr (ABL & 2048) glds16(xsrc[j] + c * SK_BK, slot + (j ^ 3) * 1024);     // ABL 2048 (hazard screen): rows 4j..4j+3 of a 16-row group stored at LDS rows (4j..4j+3) ^ 12
+            else
+            glds16(xsrc[j] + c * SK_BK, slot + j * 1024);
+            if constexpr (ABL & 256) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // ABL 256 (hazard screen): idle issue slots behind every DMA
+        }
+        if constexpr (ABL & 512) glds16(xsrc[0] + c * SK_BK, smem + XD * XB + w * 1024);   // ABL 512 (hazard screen): one more DMA into a dummy 1 KiB per wave behind the group
+    };
+    bf16x8 wr[WD][4];
+    f32x4 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (!(ABL & 1)) {
+#pragma unroll
+        for (int c = 0; c < XD - 1 && c < NCK; ++c) issueX(c);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < WD && c < NCK; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sk4_wload(wr[c][i], wp + c * 2048 + i * 512);
+    stamp();
+    sk4_static_for<0, NCK, XD, WD, MTW>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (!(ABL & 1)) {
+            if constexpr (ABL & 8) wait_vmcnt<0>(); else wait_vmcnt<sk4_wait_count(c, NCK, XD, WD, MTW, (ABL & 64) ? 1 : 0)>();      // ABL 8 (bench): drain everything
+            stamp();
+            __builtin_amdgcn_s_barrier();
+            stamp();
+            if constexpr (c + XD - 1 < NCK) issueX(c + XD - 1);
+        }
+        wait_vmcnt_w<(ABL & 1) ? 0 : sk4_wait_count_w(c, NCK, XD, WD, MTW)>(wr[c % WD]);      // W(c) landed (younger loads stay in flight)
+        stamp();
+        if constexpr (!(ABL & 2)) sk4_mfma_chunk<MTW, (EPI >= 2), (ABL & 2048) ? 12 : 0, (ABL & 4096) != 0>(smem + (c % XD) * XB + wm * (MTW * 4096), lr, g, wr[c % WD], acc);
+        else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[0][0] += (float)wr[c % WD][i][0]; }
+        }
+        if constexpr (c + WD < NCK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sk4_wload(wr[c % WD][i], wp + (c + WD) * 2048 + i * 512);
+        }
+        stamp();
+    });
+    if constexpr (ABL & 4) { if (acc[0][0] == 123.456f) out[tid] = acc[0][0]; return; }
+    const int mb = mbase + wm * MTW * 16;
+    if constexpr (EPI == 3) sk4_store_swiglu_direct<MTW>(acc, (bf16*)out, M, N / 2, mb, ntile, g, lr);
+    else if constexpr (EPI == 2) sk4_store_direct<MTW>(acc, out + (long)split * M * N, M, N, mb, ntile * 16, g, lr);
+    else if constexpr (EPI == 4) sk4_store_direct<MTW, true>(acc, out + (long)split * M * N, M, N, mb, ntile * 16, g, lr);
+    else if constexpr (EPI == 1) { static_assert(EPI != 1 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_swiglu<MT, 4>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid); }
+    else { static_assert(EPI != 0 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_tile<MT, 4>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid); }
+    if constexpr (PROF) { if (pw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); } }
+}
+extern unsigned long long* g_sk4_prof;          // stamp buffer of the PROF instantiations (libplangen_diag.so: tools/sk4_profile.py); null in production
+template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
+static void launch_sk4(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+    constexpr int XL = XD * MT * 16 * 256 + ((ABL & 512) ? 4096 * MS : 0), TL = MT * 16 * (4 * 16 + 4) * 4;
+    constexpr int LDS = XL > TL ? XL : TL;
+    auto kfn = gemm_sk4_kernel<MT, NCK, XD, WD, EPI, OCC, ABL, MS>;
+    (void)PG_DYN_LDS(kfn, LDS);
+    dim3 grid((N + 63) / 64, S, (M + MT * 16 - 1) / (MT * 16)), block(256 * MS);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, Wt, out, M, N, K, g_sk4_prof);
+}
+template <int MT, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
+static bool sk4_nck(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+    const int nck = K / SK_BK / S;
+    if (nck * S * SK_BK != K || (N & 15)) return false;
+    switch (nck) {
+        case 2: launch_sk4<MT, 2, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 4: launch_sk4<MT, 4, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 8: launch_sk4<MT, 8, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 11: launch_sk4<MT, 11, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 16: launch_sk4<MT, 16, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 22: launch_sk4<MT, 22, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        default: return false;
+    }
+}
+

@@ -19,14 +19,21 @@ struct PgTune {
     int gemm256 = 1;                                            // 256x256 eight-phase MFMA GEMM for large shapes
     int conv_halo = 1;                                          // direct halo-tile 3x3 convolution (2: lock-step variant)
     int attn_waves = 0;                                         // 4 / 8 pin the decode-attention block size
-    int attn_pair = 0;                                          // decode attention: two (row, head) items per block, longest + shortest (round 4 experiment)
-    int attn_variant = -1;                                      // unfused attention kernel variant (-1: by mode)
+    int attn_variant = 0;                                       // libplangen_diag.so only: which fused decode-attention form PgDiagHooks::attn_decode launches (0: production)
     int prefill_attn = 2;                                       // MFMA prefill attention: 2 = 128-query LDS-DMA / transpose-read kernel, 1 = 64-query kernel
     int vq_argmin_multi = 1;                                    // VQ nearest-code search: 8 latent vectors per block (0: one per block, rounds 1-3)
     int vit_attn = 2;                                           // SigLIP attention: 2 = K / V^T of a head resident in LDS (round 4), 1 = 64-key tile kernel
     int ln_wave = 1;                                            // SigLIP LayerNorm: wave-per-row register kernel (0: generic block-per-row kernel)
-    int wt_store = 0;                                           // v3 decode GEMM slabs with write-through (sc1) stores
+    int wt_store = 0;                                           // v3 decode GEMM slabs with write-through (sc1) stores (libplangen_diag.so only)
     int stream_gemm = -1;                                       // -1 auto, else bit mask: which decode GEMM classes run on the v4 LDS-DMA kernel (gemm.hip sk4_prod)
+    const struct PgDiagHooks* diag = nullptr;                   // null in libplangen_hip.so; libplangen_diag.so (diag_api.hip) points it at its variant launchers
+};
+struct SeqState;
+// Launch hooks only libplangen_diag.so fills in (measurement forms of production kernels; some produce WRONG results by construction).
+// A hook returns true when it launched something in place of the production kernel.
+struct PgDiagHooks {
+    bool (*attn_decode)(hipStream_t s, bool is_bf16, const float* qkv, int S, long slab, void* obuf, void* kc, void* vc, const float* cos_t, const float* sin_t,
+                        const SeqState& st, int M, int nh, int slots, int max_pos, float scale);
 };
 extern thread_local const PgTune* pg_tune;
 struct GemmA {
@@ -92,23 +99,14 @@ void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out,
 void launch_tile_weights(hipStream_t s, const bf16* src, bf16* dst, int N, int K);
 // dst = Wqkv [3*nh*128, K] with the rows of every q / k head re-ordered [8 | 8] per 16-row tile (RopeEpi); v rows copied
 void launch_interleave_qk(hipStream_t s, const bf16* src, bf16* dst, int nh, int K);
-int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
 
 // ---------------------------------------------------------------- LLM elementwise / attention
 // x (fp32 residual stream, in/out) += sum_s partial[s];  xn = w * (x * rsqrt(mean(x^2)+eps)).
 // partial may be null (S=0).  xn may be null (residual update only).
 template <typename T>
 void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
-                    int M, int H, float eps, int32_t* advance = nullptr,      // advance: *advance += 1 by one thread (decode step counter)
-                    uint32_t* prog = nullptr);                                // prog: device-scope ticket bumped by the launch's FIRST thread (weight_prefetch_kernel's pacing signal)
+                    int M, int H, float eps, int32_t* advance = nullptr);     // advance: *advance += 1 by one thread (decode step counter)
 
-// Run-ahead weight stream through the Infinity Cache (round 4): ONE long-running kernel on a side stream that, paced by the ticket the
-// decode step's norm launches bump, reads the NEXT GEMMs' tiled weights (default cache policy -> resident in the 256 MiB memory-side
-// cache) while the dependent chain on the main stream is in its launch ramps / norm kernels.  A hint only: results never depend on it.
-struct PfMat { const void* base; uint32_t kib; uint32_t regions; };          // kib: size in KiB; regions: consumer blocks (prefetch order interleaves them)
-struct PfLayer { PfMat m[4]; };
-void launch_weight_prefetch(hipStream_t s, const PfLayer* plan_dev, int n_layers, const uint32_t* prog, int steps, int per_step,
-                            int first, int stride, int blocks, int depth, int nt, uint32_t* stats);
 // gather rows: dst fp32 [n,H] = table[ids[idx]]  (table fp32)
 void launch_embed_gather(hipStream_t s, const float* table, const int32_t* ids, const int32_t* src_idx, float* dst,
                          int n, int H, int vocab);

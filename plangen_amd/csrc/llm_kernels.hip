@@ -5,28 +5,8 @@
 // References: SURVEY.md K1-K9, a6.1-a6.4, a7-a9 (third-party transformers Llama formulas).
 #include <type_traits>
 #include "kernels.h"
+#include "attn_decode.h"      // sum_slabs + the fused decode-attention kernel template
 
-
-// acc[v] += sum_s p[s*slab + offs[v]] with the loads of 4 slabs x NV values issued together
-// (hipcc does not unroll a runtime-S loop: a plain loop costs S dependent memory round trips).
-template <int NV>
-__device__ __forceinline__ void sum_slabs(const float* __restrict__ p, long slab, int S, const int (&offs)[NV], float (&acc)[NV]) {
-    for (int s0 = 0; s0 < S; s0 += 4) {
-        float t[4][NV];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* q = p + (long)(s0 + u < S ? s0 + u : S - 1) * slab;
-#pragma unroll
-            for (int v = 0; v < NV; ++v) t[u][v] = q[offs[v]];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (s0 + u < S) {
-#pragma unroll
-                for (int v = 0; v < NV; ++v) acc[v] += t[u][v];
-            }
-    }
-}
 
 // ------------------------------------------------------------------------------- RMSNorm
 // One 256-thread block per row.  x += sum_s partial[s]; xn = w * (x * rsqrt(mean(x^2)+eps)).
@@ -49,21 +29,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
 template <typename T, int SB>
 __global__ __launch_bounds__(512) void rmsnorm512_kernel(float* __restrict__ x, const float* __restrict__ partial,
                                                         int S, long slab, const T* __restrict__ w,
-                                                        T* __restrict__ xn, int H, float eps, int32_t* __restrict__ advance,
-                                                        uint32_t* __restrict__ prog) {
+                                                        T* __restrict__ xn, int H, float eps, int32_t* __restrict__ advance) {
     __shared__ float red[8];
-    // pacing ticket of the run-ahead weight stream: bumped FIRST (this launch starting = the GEMM in front of it has finished)
-    if (prog && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(prog, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     rmsnorm_row<T, 1, false, SB, 512>(blockIdx.x, x, partial, S, slab, w, xn, H, eps, red);
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
 }
 template <typename T>
 void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
-                    int M, int H, float eps, int32_t* advance, uint32_t* prog) {
+                    int M, int H, float eps, int32_t* advance) {
     if (M <= 0) return;
     if (H == 2048) {                               // every row count (the reduction order must not depend on M: sharded == unsharded tokens); decode loop -8 ms at bs=64, -7 ms at bs=8 vs 256 threads per row
-        if (S > 4) hipLaunchKernelGGL((rmsnorm512_kernel<T, 8>), dim3(M), dim3(512), 0, s, x, partial, S, slab, w, xn, H, eps, advance, prog);
-        else hipLaunchKernelGGL((rmsnorm512_kernel<T, 4>), dim3(M), dim3(512), 0, s, x, partial, S, slab, w, xn, H, eps, advance, prog);
+        if (S > 4) hipLaunchKernelGGL((rmsnorm512_kernel<T, 8>), dim3(M), dim3(512), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
+        else hipLaunchKernelGGL((rmsnorm512_kernel<T, 4>), dim3(M), dim3(512), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
         return;
     }
     if (H <= 1024) hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
@@ -72,100 +49,8 @@ void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long s
     else if (H <= 4096) hipLaunchKernelGGL((rmsnorm_kernel<T, 4>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
     else hipLaunchKernelGGL((rmsnorm_kernel<T, 8>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
 }
-template void launch_rmsnorm<float>(hipStream_t, float*, const float*, int, long, const float*, float*, int, int, float, int32_t*, uint32_t*);
-template void launch_rmsnorm<bf16>(hipStream_t, float*, const float*, int, long, const bf16*, bf16*, int, int, float, int32_t*, uint32_t*);
-
-// ------------------------------------------------------------------------------- run-ahead weight stream (Infinity Cache)
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-// One wave = one stream of 1 KiB wave-loads (16 B per lane, contiguous), DEPTH of them in flight, data discarded.  Trigger k of step st
-// (= the (first + k * stride)-th ticket of that step, i.e. the norm launch behind o_proj of layer k) releases layer k's list: gate|up,
-// down, the NEXT layer's qkv, in that order -- the order the main stream consumes them.  A piece index i of a matrix maps to
-// region i % R, piece i / R, so every consumer block's region gets its first pieces first.  Every spin is bounded (wall clock): a
-// prefetcher that sees no ticket for 30 ms exits; the main stream never waits for this kernel's data.
-template <int DEPTH, int NT, int REGS = 0>
-__global__ __launch_bounds__(128) void weight_prefetch_kernel(const PfLayer* __restrict__ plan, int n_layers, const uint32_t* prog, int steps,
-                                                              int per_step, int first, int stride, uint32_t* stats) {
-    __shared__ __attribute__((aligned(16))) char sink[2][1024];
-    const int lane = threadIdx.x & 63;
-    const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.x * (blockDim.x >> 6);
-    unsigned done_layers = 0, skipped = 0;
-    const long total = (long)steps * n_layers;
-    long k = 0;                                                 // global trigger index = st * n_layers + layer
-    unsigned long long t_last = wall_clock64();
-    while (k < total) {
-        const int st = (int)(k / n_layers), l = (int)(k % n_layers);
-        const unsigned target = (unsigned)st * per_step + first + l * stride;
-        unsigned p = 0;
-        if (per_step > 0)                                       // per_step == 0: free-running stressor (tools/sk4_load_stress.py), no tickets
-        for (;;) {                                              // relaxed poll by every lane of one load (a wave-uniform scalar would be cached)
-            p = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p >= target) break;
-            __builtin_amdgcn_s_sleep(16);
-            // no ticket for 30 ms (100 MHz clock): the loop is over or was aborted.  Before the FIRST ticket the bound is 2 ms: a first ticket that late
-            // means this kernel sits on the decode stream's own hardware queue and is what keeps the loop from starting -- leave at once
-            if (wall_clock64() - t_last > (k == 0 ? 200000ull : 3000000ull)) {
-                if (stats && threadIdx.x == 0 && blockIdx.x == 0) { stats[0] = done_layers; stats[1] = skipped; stats[2] = 1; }
-                return;
-            }
-        }
-        t_last = wall_clock64();
-        // lagging: when the main stream is already past LATER triggers, jump to the newest one (its weights are what is needed next)
-        if (per_step > 0) {
-            const unsigned into = p - (unsigned)st * per_step;                      // tickets of this step seen so far (may exceed per_step)
-            long knew = k;
-            if (into >= (unsigned)per_step) knew = (long)(st + into / per_step) * n_layers;       // at least one whole step ahead: restart at that step's layer 0 trigger
-            else if (into >= (unsigned)(first + stride)) { const int lmax = (int)((into - first) / stride); knew = (long)st * n_layers + (lmax < n_layers ? lmax : n_layers - 1); }
-            if (knew > k) { skipped += (unsigned)(knew - k); k = knew; continue; }
-        }
-        const PfLayer& L = plan[l];
-#pragma unroll 1
-        for (int mi = 0; mi < 4; ++mi) {
-            const char* base = (const char*)L.m[mi].base;
-            const unsigned npieces = L.m[mi].kib, R = L.m[mi].regions ? L.m[mi].regions : 1u;
-            if (!base) continue;
-            const unsigned per_region = npieces / R;                                 // pieces beyond R * per_region (none for the decode shapes) are left cold
-            unsigned i = wid;
-            const unsigned lim = per_region * R;
-            if constexpr (REGS) {       // stressor variant: plain register loads in groups of 8 (no LDS-DMA from this kernel)
-                for (; i < lim; i += nw * 8) {
-                    u32x4 t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const unsigned ii = i + u * nw < lim ? i + u * nw : i;
-                        const char* ptr = base + ((size_t)(ii % R) * per_region + ii / R) * 1024 + lane * 16;
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(t[u]) : "v"(ptr) : "memory");
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) asm volatile("" :: "v"(t[u]));
-                }
-            } else
-            for (; i < lim; i += nw) {
-                const unsigned r = i % R, j = i / R;
-                const char* ptr = base + ((size_t)r * per_region + j) * 1024 + lane * 16;
-                // LDS-DMA into a 1 KiB per-wave sink nobody reads: no VGPR is written, so nothing the compiler re-uses can be overwritten by
-                // a load that lands later (a register-destination asm load whose result is "dead" gets its register recycled while in flight)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)ptr, (lds_ptr_t)sink[threadIdx.x >> 6], 16, 0, NT ? 2 : 0);
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DEPTH - 1) : "memory");
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ++done_layers;
-        ++k;
-    }
-    if (stats && threadIdx.x == 0 && blockIdx.x == 0) { stats[0] = done_layers; stats[1] = skipped; stats[2] = 0; }
-}
-void launch_weight_prefetch(hipStream_t s, const PfLayer* plan_dev, int n_layers, const uint32_t* prog, int steps, int per_step,
-                            int first, int stride, int blocks, int depth, int nt, uint32_t* stats) {
-    if (steps <= 0 || n_layers <= 0) return;
-    dim3 g(blocks), b(128);
-#define PG_PF(D, N) hipLaunchKernelGGL((weight_prefetch_kernel<D, N>), g, b, 0, s, plan_dev, n_layers, prog, steps, per_step, first, stride, stats)
-    if (depth < 0) { hipLaunchKernelGGL((weight_prefetch_kernel<8, 0, 1>), g, b, 0, s, plan_dev, n_layers, prog, steps, per_step, first, stride, stats); return; }
-    if (nt) { if (depth >= 32) PG_PF(32, 1); else if (depth >= 16) PG_PF(16, 1); else PG_PF(8, 1); }
-    else { if (depth >= 32) PG_PF(32, 0); else if (depth >= 16) PG_PF(16, 0); else PG_PF(8, 0); }
-#undef PG_PF
-}
+template void launch_rmsnorm<float>(hipStream_t, float*, const float*, int, long, const float*, float*, int, int, float, int32_t*);
+template void launch_rmsnorm<bf16>(hipStream_t, float*, const float*, int, long, const bf16*, bf16*, int, int, float, int32_t*);
 
 // ------------------------------------------------------------------------------- row movers
 // dst[t] = table[ids[src_idx ? src_idx[t] : t]]   (K1; packed left-pad-free gather)
@@ -388,304 +273,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const T* __restrict__ qbuf, T
         ET<T>::st(obuf + (long)qi * HD + head * 128 + tid, num / den);
     }
 }
-// ------------------------------------------------------------------------------- fused decode attention
-// Decode step only: one block per (row, head) does RoPE(q), RoPE(k), appends K/V at slot
-// len+n_dec (reading the QKV GEMM's fp32 split-K slabs directly), then streams that row-head's
-// cached K/V (non-temporal 16-byte loads: the cache is read exactly once per step) and merges
-// the new key, which never leaves LDS, as one more online-softmax state.  Replaces
-// rope_kv_kernel + attn_kernel (one launch and the q round trip less per layer).
-// Round 2 (in-loop ablation, profiles/r02_c_attention_prologue.md): the prologue costs 6.6 us of the 69.6 us launch -- 3.6 us the
-// slab loads, 2.4 us the K/V append stores (8 192 scattered 128-byte line writes per launch), 0.6 us the rest -- because at kernel
-// start (and when the second round of blocks starts) every resident block is in its prologue and nothing streams.  So: the FIRST
-// K/V chunk of every wave is issued BEFORE the prologue's dependent chain (slab loads -> RoPE -> LDS -> barrier) and consumed right
-// after the barrier, in the loop's own kv[] / vv[] registers (no double buffer, still 4 waves per SIMD); the append is ONE
-// 8-byte-per-lane store instruction per block, issued after the barrier.  Loop 1800 -> 1783 ms at bs=64.
-template <typename T, int UN, int NW, int ABL = 0>      // ABL (timing ablations, WRONG results): 1 no K/V append store, 2 no slab / cos / sin loads, 4 no merge epilogue
-__global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float* __restrict__ qkv, int S, long slab,
-                                                              T* __restrict__ obuf, T* __restrict__ kc, T* __restrict__ vc,
-                                                              const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                              SeqState st, int nh, int slots, int max_pos, float scale) {
-    constexpr int EPV = ET<T>::EPV, LPK = 128 / EPV, KPI = 64 / LPK, NST = NW * KPI;
-    __shared__ float s_o[NST][128];
-    __shared__ float s_m[NST], s_l[NST];
-    __shared__ __attribute__((aligned(16))) float s_q[128];
-    __shared__ float s_k[128], s_v[128];
-    __shared__ float s_new;
-    // ABL bit 32 (round 4, `attn_pair`): the grid has M / 2 rows of blocks and every block processes TWO (row, head) items -- rank y of the
-    // longest-first order, then rank M - 1 - y -- so all blocks carry (longest + shortest) ~ the same number of keys and the second item's
-    // prologue runs while the CU's other blocks stream (the one-item launch has every block in its prologue at once and a tail of short rows)
-    constexpr int NIT = (ABL & 32) ? 2 : 1;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int head = blockIdx.x;
-#pragma unroll 1
-    for (int it = 0; it < NIT; ++it) {
-    const int yi = it == 0 ? (int)blockIdx.y : (int)(2 * gridDim.y - 1 - blockIdx.y);
-    const int row = st.row_order ? st.row_order[yi] : yi;
-    const int grp = l / LPK, lk = l % LPK;
-    const int slot = st.len[row] + *st.n_dec;
-    const int nprev = slot < slots ? slot : slots - 1;
-    const int HD = nh * 128;
-    const long cbase = ((long)row * nh + head) * slots * 128;
-    constexpr int KPW = KPI * UN;
-    const bool sh = st.shared_len > 0 && (row & 1);
-    const int kstart = sh ? (st.shared_len < nprev ? st.shared_len : nprev) : 0;
-    const long sbase = ((long)st.shared_row * nh + head) * (long)slots * 128 + lk * EPV;
-    const T* const kpriv = kc + cbase + lk * EPV; const T* const vpriv = vc + cbase + lk * EPV;
-    const T* const kshr = kc + sbase; const T* const vshr = vc + sbase;
-
-    u32x4 kv[UN], vv[UN];
-    auto issue = [&](const T* kb, const T* vb, int base, int k1, auto ntl) {
-        constexpr bool NTL = decltype(ntl)::value;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            int key = base + u * KPI + grp;
-            key = key < k1 ? key : k1 - 1;
-            key = key < 0 ? 0 : key;                                 // k1 == 0 (peeled issue of an empty segment): slot 0 is always mapped
-            kv[u] = NTL ? __builtin_nontemporal_load((const u32x4*)(kb + (long)key * 128)) : *(const u32x4*)(kb + (long)key * 128);
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            int key = base + u * KPI + grp;
-            key = key < k1 ? key : k1 - 1;
-            key = key < 0 ? 0 : key;
-            vv[u] = NTL ? __builtin_nontemporal_load((const u32x4*)(vb + (long)key * 128)) : *(const u32x4*)(vb + (long)key * 128);
-        }
-    };
-    // first chunk of the first segment (shared prefix for uncond rows, private stream otherwise): no dependence on q
-    const int seg_k1 = sh ? kstart : nprev;
-    const int base0 = w * KPW;
-    const bool have0 = base0 < seg_k1;
-    // wave 0: the prologue's slab / cos / sin loads go out FIRST and straight-line (a runtime-S loop makes the compiler drain vmcnt
-    // at its header, which serialised the peeled chunk in front of the slab loads), then every wave's first K/V chunk; the slab
-    // values are waited for with the K/V chunk still in flight behind them.
-    const int o6[6] = {0, 64, HD, HD + 64, 2 * HD, 2 * HD + 64};
-    float t4[4][6], cs = 0.f, sn = 0.f;
-    int pos = st.pos_off[row] + slot;
-    if (pos >= max_pos) pos = max_pos - 1;
-    const float* const qrow = qkv + (long)row * 3 * HD + head * 128 + (tid & 63);
-    if (tid < 64) {
-        if constexpr (ABL & 2) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 6; ++v) t4[u][v] = 0.01f * (float)(tid + v);
-            cs = 1.f; sn = 0.f;
-        } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* qq = qrow + (long)(u < S ? u : S - 1) * slab;
-#pragma unroll
-            for (int v = 0; v < 6; ++v) t4[u][v] = qq[o6[v]];
-        }
-        cs = cos_t[(long)pos * 64 + tid]; sn = sin_t[(long)pos * 64 + tid];
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);          // the slab sums must not be scheduled (with their vmcnt waits) in front of the K/V issue
-    // UNCONDITIONAL (addresses clamped into the segment): behind a branch the compiler must count wave 0's slab waits for the path
-    // that issued nothing, i.e. 14 ops too strict on the path that did -- the RoPE prologue then waited for 12 of the 14 K/V loads
-    // (3.5 us per launch in the in-loop ablation)
-    if (sh) issue(kshr, vshr, base0, seg_k1, std::false_type{}); else issue(kpriv, vpriv, base0, seg_k1, std::true_type{});
-    __builtin_amdgcn_sched_barrier(0);
-
-    if (tid < 64) {
-        const int j = tid;
-        float a6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // opaque touch: the loaded slab values may not be consumed (and waited for) before this point in program order
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 6; ++v) asm volatile("" : "+v"(t4[u][v])::"memory");
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < S) {
-#pragma unroll
-                for (int v = 0; v < 6; ++v) a6[v] += t4[u][v];
-            }
-        if (S > 4) sum_slabs<6>(qrow + 4 * slab, slab, S - 4, o6, a6);
-        const float q0 = a6[0], q1 = a6[1], k0 = a6[2], k1 = a6[3], v0 = a6[4], v1 = a6[5];
-        const float c = cs;
-        s_q[j] = ET<T>::round(q0 * c - q1 * sn) * scale;
-        s_q[j + 64] = ET<T>::round(q1 * c + q0 * sn) * scale;
-        const float kr0 = ET<T>::round(k0 * c - k1 * sn), kr1 = ET<T>::round(k1 * c + k0 * sn);
-        const float vr0 = ET<T>::round(v0), vr1 = ET<T>::round(v1);
-        s_k[j] = kr0; s_k[j + 64] = kr1; s_v[j] = vr0; s_v[j + 64] = vr1;
-    }
-    __syncthreads();
-    if (w == 0) {
-        float d = s_q[l] * s_k[l] + s_q[l + 64] * s_k[l + 64];
-        d = wave_sum(d);
-        if (l == 0) s_new = d;
-    }
-    float q[EPV];
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) q[e] = s_q[lk * EPV + e];
-    float m_run = -INFINITY, l_run = 0.f, o[EPV];
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) o[e] = 0.f;
-    auto consume = [&](int base, int k1) {
-        float sc[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            float kf[EPV]; ET<T>::unpack(kv[u], kf);
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) d = fmaf(q[e], kf[e], d);
-#pragma unroll
-            for (int o_ = LPK / 2; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
-            sc[u] = (base + u * KPI + grp < k1) ? d : -INFINITY;
-        }
-        float mx = m_run;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) mx = fmaxf(mx, sc[u]);
-        if (mx > -INFINITY) {
-            const float alpha = __expf(m_run - mx);
-            l_run *= alpha;
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) o[e] *= alpha;
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const float p = __expf(sc[u] - mx);
-                l_run += p;
-                float vf[EPV]; ET<T>::unpack(vv[u], vf);
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) o[e] = fmaf(p, vf[e], o[e]);
-            }
-            m_run = mx;
-        }
-    };
-    // explicitly software-pipelined form of the loop (ABL bit 16, experiment): K(i+1) goes out BEFORE the wait for V(i), so one of the
-    // two round trips of an iteration runs under the other's arithmetic; loads unconditional (clamped) so the counted waits stay exact
-    auto issueK = [&](const T* kb, int base, int k1) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            int key = base + u * KPI + grp;
-            key = key < k1 ? key : k1 - 1;
-            kv[u] = __builtin_nontemporal_load((const u32x4*)(kb + (long)key * 128));
-        }
-    };
-    auto issueV = [&](const T* vb, int base, int k1) {
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            int key = base + u * KPI + grp;
-            key = key < k1 ? key : k1 - 1;
-            vv[u] = __builtin_nontemporal_load((const u32x4*)(vb + (long)key * 128));
-        }
-    };
-    auto run_pipe = [&](const T* kb, const T* vb, int kfirst, int k1) {
-        if (kfirst >= k1) return;
-        issueK(kb, kfirst, k1);
-        for (int base = kfirst; base < k1; base += NW * KPW) {
-            issueV(vb, base, k1);
-            float sc[UN];
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                float kf[EPV]; ET<T>::unpack(kv[u], kf);
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) d = fmaf(q[e], kf[e], d);
-#pragma unroll
-                for (int o_ = LPK / 2; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
-                sc[u] = (base + u * KPI + grp < k1) ? d : -INFINITY;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            issueK(kb, base + NW * KPW, k1);                         // next chunk's K (clamped to the last key past the end: one cache line)
-            __builtin_amdgcn_sched_barrier(0);
-            float mx = m_run;
-#pragma unroll
-            for (int u = 0; u < UN; ++u) mx = fmaxf(mx, sc[u]);
-            const float mxs = (mx > -INFINITY) ? mx : 0.f;
-            const float alpha = __expf(m_run - mxs);
-            l_run *= alpha;
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) o[e] *= alpha;
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const float p = __expf(sc[u] - mxs);
-                l_run += p;
-                float vf[EPV]; ET<T>::unpack(vv[u], vf);
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) o[e] = fmaf(p, vf[e], o[e]);
-            }
-            m_run = mx;
-        }
-    };
-    auto run = [&](const T* kb, const T* vb, int kfirst, int k1, auto ntl) {
-        if constexpr ((ABL & 16) != 0 && decltype(ntl)::value) { run_pipe(kb, vb, kfirst, k1); return; }
-        for (int base = kfirst; base < k1; base += NW * KPW) { issue(kb, vb, base, k1, ntl); consume(base, k1); }
-    };
-    if (have0) consume(base0, seg_k1);
-    if (sh) {
-        run(kshr, vshr, base0 + NW * KPW, kstart, std::false_type{});
-        run(kpriv, vpriv, kstart + w * KPW, nprev, std::true_type{});
-    } else {
-        run(kpriv, vpriv, base0 + NW * KPW, nprev, std::true_type{});
-    }
-    if constexpr (ABL & 4) {
-        float acc = l_run + m_run;
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) acc += o[e];
-        if (acc == 123.456f) ET<T>::st(obuf + (long)row * HD + head * 128 + tid % 128, acc);
-        return;
-    }
-    const int stt = w * KPI + grp;
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) s_o[stt][lk * EPV + e] = o[e];
-    if (lk == 0) { s_m[stt] = m_run; s_l[stt] = l_run; }
-    __syncthreads();
-    if (tid < 128) {
-        float Mx = s_new;
-#pragma unroll
-        for (int i = 0; i < NST; ++i) Mx = fmaxf(Mx, s_m[i]);
-        const float fn = __expf(s_new - Mx);
-        float num = fn * s_v[tid], den = fn;
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const float f = (s_m[i] > -INFINITY) ? __expf(s_m[i] - Mx) : 0.f;
-            num = fmaf(f, s_o[i][tid], num);
-            den = fmaf(f, s_l[i], den);
-        }
-        ET<T>::st(obuf + (long)row * HD + head * 128 + tid, num / den);
-    }
-    // K/V append, LAST thing the block does: ONE store instruction (lanes 0-31 the K row, 32-63 the V row, 4 elements each) from the
-    // RoPE'd row still sitting in LDS.  Nothing waits behind it: issued right after the prologue it sat in front of wave 0's first
-    // `vmcnt` wait (counted in order), and the store's acknowledgement cost 2.4 us of every launch (in-loop ablation, 34 ms per loop).
-    if (!(ABL & 1) && tid < 64 && slot < slots) {
-        const float* src = (l < 32 ? s_k : s_v) + (l & 31) * 4;
-        T* dst = (l < 32 ? kc : vc) + cbase + (long)slot * 128 + (l & 31) * 4;
-        if constexpr (sizeof(T) == 2) {
-            u32x2 pk; pk.x = pack_bf16x2(src[0], src[1]); pk.y = pack_bf16x2(src[2], src[3]);
-            *(u32x2*)dst = pk;
-        } else {
-            *(f32x4*)dst = *(const f32x4*)src;
-        }
-    }
-    if constexpr (NIT > 1) __syncthreads();          // the append and the merge have read this item's LDS state
-    }
-}
 template <typename T>
 void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc,
                               const float* cos_t, const float* sin_t, SeqState st, int M, int nh, int slots,
                               int max_pos, float scale) {
     if (M <= 0) return;
-    // few (row, head) blocks (small batch): eight waves per block keep 2x the K/V bytes in flight per CU
-    // Production: the software-pipelined loop (ABL bit 16): 8-wave blocks 5 deep when the launch has few (row, head) blocks (small batch:
-    // 2x the K/V bytes in flight per CU), 4-wave blocks 6 deep otherwise (7 deep spills in the pipelined form).  attn_variant 100 = the
-    // round-2 non-pipelined 7-deep kernel, 101-107 = timing ablations of the production kernel (results wrong by construction).
+    // The software-pipelined loop (template argument ABL = 16): 8-wave blocks 5 deep when the launch has few (row, head) blocks (small batch:
+    // 2x the K/V bytes in flight per CU), 4-wave blocks 6 deep otherwise (7 deep spills in the pipelined form).  Only these two forms are
+    // instantiated in libplangen_hip.so; the older non-pipelined kernel and the timing ablations live in libplangen_diag.so (diag_attn.hip),
+    // which registers itself in PgTune::diag.
+    if (pg_tune->diag && pg_tune->diag->attn_decode && pg_tune->diag->attn_decode(s, std::is_same<T, bf16>::value, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, M, nh, slots, max_pos, scale)) return;
 #define ATT_LAUNCH(U, W, A) hipLaunchKernelGGL((attn_decode_fused_kernel<T, U, W, A>), dim3(nh, M), dim3(64 * W), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, nh, slots, max_pos, scale)
-    const int av = pg_tune->attn_variant;
     const bool small = (M * nh <= 512 && pg_tune->attn_waves != 4) || pg_tune->attn_waves == 8;
-    if (av == 100) { if (small) ATT_LAUNCH(7, 8, 0); else ATT_LAUNCH(7, 4, 0); }
-    else if (av > 100 && av < 108 && !small) {
-        switch (av) {
-            case 101: ATT_LAUNCH(6, 4, 17); break;
-            case 102: ATT_LAUNCH(6, 4, 18); break;
-            case 103: ATT_LAUNCH(6, 4, 19); break;
-            case 104: ATT_LAUNCH(6, 4, 20); break;
-            default: ATT_LAUNCH(6, 4, 23); break;
-        }
-    } else if (small) ATT_LAUNCH(5, 8, 16);
-    else if (pg_tune->attn_pair && (M & 1) == 0 && st.row_order)
-        hipLaunchKernelGGL((attn_decode_fused_kernel<T, 6, 4, 16 | 32>), dim3(nh, M / 2), dim3(256), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, nh, slots, max_pos, scale);
+    if (small) ATT_LAUNCH(5, 8, 16);
     else ATT_LAUNCH(6, 4, 16);
 #undef ATT_LAUNCH
 }
@@ -697,14 +297,9 @@ void launch_attn(hipStream_t s, const T* qbuf, T* obuf, const T* kc, const T* vc
                  int M, int nh, int slots, float scale) {
     if (M <= 0) return;
     dim3 grid(M, nh), block(256);
-    const int variant = pg_tune->attn_variant >= 0 ? pg_tune->attn_variant : (mode == 0 ? 1 : 0);
-    switch (variant) {
-        case 1: hipLaunchKernelGGL((attn_kernel<T, 8, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
-        case 2: hipLaunchKernelGGL((attn_kernel<T, 4, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
-        case 3: hipLaunchKernelGGL((attn_kernel<T, 4, false>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
-        case 4: hipLaunchKernelGGL((attn_kernel<T, 16, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
-        default: hipLaunchKernelGGL((attn_kernel<T, 8, false>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale); break;
-    }
+    // decode (mode 0): 8 keys per lane group in flight, non-temporal K/V loads (read once per step); prefill: cached loads
+    if (mode == 0) hipLaunchKernelGGL((attn_kernel<T, 8, true>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale);
+    else hipLaunchKernelGGL((attn_kernel<T, 8, false>), grid, block, 0, s, qbuf, obuf, kc, vc, st, mode, nh, slots, scale);
 }
 template void launch_attn<float>(hipStream_t, const float*, float*, const float*, const float*, SeqState, int, int, int, int, float);
 template void launch_attn<bf16>(hipStream_t, const bf16*, bf16*, const bf16*, const bf16*, SeqState, int, int, int, int, float);

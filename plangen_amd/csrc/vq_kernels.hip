@@ -326,15 +326,15 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
     __shared__ float sv[4]; __shared__ int si[4];
     const int r = blockIdx.x, tid = threadIdx.x;
     float zn[8]; float ss = 0.f;
-    for (int d = 0; d < D; ++d) { zn[d] = z[(long)r * D + d]; ss += zn[d] * zn[d]; }
+    for (int d = 0; d < D; ++d) { zn[d] = z[(long)r * D + d]; ss = fmaf(zn[d], zn[d], ss); }
     const float nrm = fmaxf(sqrtf(ss), 1e-12f);
     float zz = 0.f;
-    for (int d = 0; d < D; ++d) { zn[d] /= nrm; zz += zn[d] * zn[d]; }
+    for (int d = 0; d < D; ++d) { zn[d] /= nrm; zz = fmaf(zn[d], zn[d], zz); }
     float best = INFINITY; int bi = 0x7fffffff;
     for (int v = tid; v < V; v += 256) {
         float ee = 0.f, dot = 0.f;
-        for (int d = 0; d < D; ++d) { const float e = cb[(long)v * D + d]; ee += e * e; dot += zn[d] * e; }
-        const float dist = zz + ee - 2.f * dot;
+        for (int d = 0; d < D; ++d) { const float e = cb[(long)v * D + d]; ee = fmaf(e, e, ee); dot = fmaf(zn[d], e, dot); }
+        const float dist = fmaf(-2.f, dot, zz + ee);
         if (dist < best) { best = dist; bi = v; }
     }
 #pragma unroll
@@ -352,8 +352,9 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
 }
 // Round 4: ZB latent vectors per block -- every codebook entry a thread loads (and its |e|^2) serves ZB distance computations instead of one
 // (the one-vector kernel above re-reads the 512 KiB codebook from L2 once per latent vector: 19 GB for 64 images, 7.8 ms).  The arithmetic
-// of a (vector, code) pair is the SAME expression sequence as above (normalisation, ee, dot, zz + ee - 2 dot, first minimum), so the
-// indices are identical (asserted against the reference fixtures and against the one-vector kernel in tests/test_gpu_ops.py).
+// of a (vector, code) pair is the SAME expression sequence as above (normalisation, ee, dot, zz + ee - 2 dot, first minimum), spelled as
+// explicit fmaf chains in BOTH kernels so the equality holds by construction rather than by hipcc making the same -ffp-contract choices in
+// two differently shaped loops; asserted against the reference fixtures and against the one-vector kernel (tests/test_gpu_ops.py).
 template <int ZB>
 __global__ __launch_bounds__(256) void vq_argmin_multi_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                              int64_t* __restrict__ idx, int n, int V) {
@@ -365,10 +366,10 @@ __global__ __launch_bounds__(256) void vq_argmin_multi_kernel(const float* __res
     for (int j = 0; j < ZB; ++j) {
         const int r = r0 + j < n ? r0 + j : n - 1;
         float ss = 0.f;
-        for (int d = 0; d < D; ++d) { zn[j][d] = z[(long)r * D + d]; ss += zn[j][d] * zn[j][d]; }
+        for (int d = 0; d < D; ++d) { zn[j][d] = z[(long)r * D + d]; ss = fmaf(zn[j][d], zn[j][d], ss); }
         const float nrm = fmaxf(sqrtf(ss), 1e-12f);
         zz[j] = 0.f;
-        for (int d = 0; d < D; ++d) { zn[j][d] /= nrm; zz[j] += zn[j][d] * zn[j][d]; }
+        for (int d = 0; d < D; ++d) { zn[j][d] /= nrm; zz[j] = fmaf(zn[j][d], zn[j][d], zz[j]); }
         best[j] = INFINITY; bi[j] = 0x7fffffff;
     }
     for (int v = tid; v < V; v += 256) {
@@ -376,12 +377,12 @@ __global__ __launch_bounds__(256) void vq_argmin_multi_kernel(const float* __res
         const f32x4 e0 = *(const f32x4*)(cb + (long)v * D), e1 = *(const f32x4*)(cb + (long)v * D + 4);
         e[0] = e0[0]; e[1] = e0[1]; e[2] = e0[2]; e[3] = e0[3]; e[4] = e1[0]; e[5] = e1[1]; e[6] = e1[2]; e[7] = e1[3];
         float ee = 0.f;
-        for (int d = 0; d < D; ++d) ee += e[d] * e[d];
+        for (int d = 0; d < D; ++d) ee = fmaf(e[d], e[d], ee);
 #pragma unroll
         for (int j = 0; j < ZB; ++j) {
             float dot = 0.f;
-            for (int d = 0; d < D; ++d) dot += zn[j][d] * e[d];
-            const float dist = zz[j] + ee - 2.f * dot;
+            for (int d = 0; d < D; ++d) dot = fmaf(zn[j][d], e[d], dot);
+            const float dist = fmaf(-2.f, dot, zz[j] + ee);
             if (dist < best[j]) { best[j] = dist; bi[j] = v; }
         }
     }

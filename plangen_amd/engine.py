@@ -41,10 +41,13 @@ class Engine:
     def __init__(self, cfg: PlanGenConfig, dtype: str = "bf16", max_rows: int = 16, max_prompt: int = 256,
                  max_new: Optional[int] = None, max_images: Optional[int] = None, with_lm_head: bool = False,
                  with_vq_encoder: bool = False, with_vision: bool = False, max_vision_images: Optional[int] = None,
-                 device: int = 0):
+                 device: int = 0, diag: bool = False):
         if not torch.cuda.is_available():
             raise PlanGenError("plangen_amd.Engine needs an MI355X (no CPU fallback)")
-        self.lib = _lib.load()
+        # diag=True (tools/, bench.py's instrumented pass, hazard-screen tests): the handle lives in libplangen_diag.so -- the same object
+        # code plus pg_diag_set_option; the product path never passes it
+        self.diag = bool(diag)
+        self.lib = _lib.load_diag() if diag else _lib.load()
         self.cfg = cfg
         self.dtype = dtype
         self.code = PG_BF16 if dtype == "bf16" else PG_F32
@@ -115,6 +118,12 @@ class Engine:
 
     def set_option(self, key: str, value: int):
         self._check(self.lib.pg_set_option(self.h, key.encode(), int(value)), "pg_set_option")
+
+    def set_diag_option(self, key: str, value: int):
+        """Measurement-only switches of libplangen_diag.so (skip_attn, attn_variant, ...): needs Engine(diag=True)."""
+        if not self.diag:
+            raise PlanGenError("set_diag_option needs an engine created with diag=True (libplangen_diag.so)")
+        self._check(self.lib.pg_diag_set_option(self.h, key.encode(), int(value)), "pg_diag_set_option")
 
     def timing(self) -> dict:
         t = _lib.pg_timing()

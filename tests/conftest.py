@@ -72,7 +72,7 @@ def _background_memory_load():
     import threading
     import time
     from plangen_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_diag()          # the stressor kernel lives in the diagnostics library; the engines under test stay in libplangen_hip.so
     stop = threading.Event()
     blocks, depth = int(os.environ.get("PG_BG_BLOCKS", "256")), int(os.environ.get("PG_BG_DEPTH", "16"))
 

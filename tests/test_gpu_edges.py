@@ -302,47 +302,14 @@ def test_bf16_flash_prefill_at_tile_boundaries(tiny_cfg, tiny_weights):
     assert (outs[2] - outs[1]).abs().max().item() < 0.03 * scale
 
 
-def test_runahead_weight_prefetcher_changes_nothing_and_keeps_pace():
-    """Option `mall_prefetch` (round 4, off by default: measured slower, profiles/r04_b): a long-running kernel on its own stream reads
-    the next GEMMs' weights while the decode loop runs, paced by a device ticket.  It is a hint -- the sampled tokens must be identical
-    with and without it -- and its bookkeeping must add up: one layer list per (forward, layer), nothing skipped, no spin timed out.
-    (This is also the concurrent-memory-load condition under which the decode GEMM's epilogue store hazard showed, profiles/r04_a.)"""
-    from bench import synth_prompts
-    from plangen_amd.config import PlanGenConfig
-    from plangen_amd.engine import Engine
-    cfg = PlanGenConfig.janus_pro_1b()
-    B, L, T = 16, 64, 24
-    e = Engine(cfg, dtype="bf16", max_rows=2 * B, max_prompt=L, max_new=32, max_images=1)
-    e.init_synthetic(seed=0)
-    ids, mask = synth_prompts(B, L, cfg.vocab, cfg.pad_id, seed=2)
-    pad = Engine.pad_len_from_mask(mask, L)
-    outs = []
-    for on in (0, 1, 1, 0):
-        e.set_option("mall_prefetch", on)
-        e.prefill(ids, pad)
-        outs.append(e.decode_image_tokens(T=T, cfg_weight=5.0, temperature=1.0, seed=5).cpu())
-        if on:
-            torch.cuda.synchronize()
-            done, skipped, timed_out = e.debug_read("pf_stats", 0, 4, torch.int32).cpu().tolist()[:3]
-            if timed_out:
-                # a bounded wait gave up and the prefetcher left early: its side stream was mapped onto the decode stream's own hardware
-                # queue (HIP has only a few), or the first forward of a fresh process was slower than the 2 ms first-ticket bound (lazy
-                # code-object loading).  Legitimate -- it is a hint -- and the tokens below must still be identical.
-                assert done + skipped <= (T - 1) * cfg.n_layers
-                continue
-            assert done + skipped == (T - 1) * cfg.n_layers, (done, skipped, timed_out)
-    e.set_option("mall_prefetch", 0)
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
-    e.close()
-
-
 def test_persistent_chain_skeleton_barriers_complete():
     """The measured skeleton of the persistent decode chain (chain.hip, profiles/r04_c): 256 workgroups, three hierarchical grid
     barriers per launch, run-ahead register-ring weight stream.  Every spin is bounded; no barrier may give up and the launch
     sequence must finish (a lost arrival would show as give-ups, not as a hang)."""
     import ctypes as C
     from conftest import ROOT
-    lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+    from plangen_amd import _lib
+    lib = _lib.load_diag()
     lib.pg_bench_chain_skeleton.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
     for mode in (1, 3, 5):
         us, err = C.c_float(0), C.c_uint(0)

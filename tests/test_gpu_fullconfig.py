@@ -1,0 +1,242 @@
+"""GPU: THE REAL CONFIGURATION AT ONCE -- depth x prompt length x decode length (x batch) -- against the transformers-driven fixture
+tests/golden/sample_image_fullconfig.npz (oracle/make_golden.py::golden_full_config): Janus-Pro-1B width, depth (24 layers) and vocabulary
+(102 400), full VQ-16; 2 CFG pairs with cond lengths 256 / 160 left-padded to L = 256 and the shared 96-token negative prompt; all 576 greedy
+steps (contexts 257-831); pixels from the reference's OWN ``VQ_models["VQ-16"].decode_code`` on the generated tokens.
+
+This is ``north_star``'s acceptance statement ("bit-exact indices, pixel-MSE <= 1e-4 vs reference") at the shape it is stated on; the other
+full-size files cap one of {depth, prompt, steps, rows} (plangen_base.py:525-607, vq_model.py:505-508):
+
+  1. PG_F32 through ``System.t2i`` (collate -> prefill -> 576-step loop -> decode_code): all 2 x 576 free-running tokens bit-exact, pixel
+     MSE <= 1e-4 against the oracle's image of the same tokens, the reference's own pooled image / crops within tolerance;
+  2. PG_BF16 teacher-forced: logit error statistics, reported separately for steps >= 400 (contexts 656-831); pixels of the oracle's tokens
+     within MSE <= 1e-4;
+  3. bench-shape placement: the same two pairs as images 62 and 63 of a 64-pair batch (the other 62 from ``bench.synth_prompts``) on an
+     engine created exactly like bench.py's (max_rows 128, max_prompt 256, max_new 576): PG_F32 tokens of those two images == the fixture
+     (rows are independent).  That reads rows 124-127 x layer 23 x slots up to 831 -- the top of the 43 GB (f32) / 21.5 GB (bf16) KV cache;
+     PG_BF16 teacher-forced logits of those two images inside the same bounds as test 2 (the bs=64 kernel instantiations at depth 24).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+_S = {}
+F32_LOGIT_TOL = 5e-3          # 24 layers of fp32 with a different summation order (measured: see the printed value)
+BF16_MAX, BF16_P99 = 0.45, 0.30      # teacher-forced |logit error| bounds, 1.5x the values measured on MI355X (printed by the test; round 5)
+
+
+def _setup():
+    if not _S:
+        from plangen_amd.config import PlanGenConfig
+        g = load_golden("sample_image_fullconfig.npz")
+        ocfg = R.OracleCfg()
+        W = R.make_weights(ocfg, seed=int(g["seed_w"]), with_lm_head=False)
+        ws = float(sum(v.double().abs().sum() for v in W.values()))
+        assert abs(ws - float(g["wsum"])) < 1e-6 * ws
+        _S.update(W=W, g=g, ocfg=ocfg, cfg=PlanGenConfig.janus_pro_1b())
+    return _S
+
+
+def _prompts(g):
+    ids = torch.from_numpy(g["ids"].astype(np.int32))
+    pad = [int(p) for p in g["pad"]]
+    cond = [ids[r, pad[r]:].tolist() for r in (0, 2)]
+    neg = ids[1, pad[1]:].tolist()
+    assert ids[3, pad[3]:].tolist() == neg
+    return ids, pad, cond, neg
+
+
+def _oracle_image(s):
+    """The oracle's pixels of the fixture's tokens (CPU, ~10 s): the restatement equals the reference's VQ-16 to 5e-5 at generation time and
+    is re-pinned here against the stored pooled image / crops of the reference itself."""
+    if "img" not in s:
+        g = s["g"]
+        img = R.vq_decode_code(s["W"], s["ocfg"], torch.from_numpy(g["tokens"]))
+        assert (torch.nn.functional.avg_pool2d(img, 8) - torch.from_numpy(g["pooled"])).abs().max().item() < 5e-5
+        assert (img[0, :, 100:132, 200:232] - torch.from_numpy(g["crop0"])).abs().max().item() < 5e-5
+        s["img"] = img
+    return s["img"]
+
+
+def _check_pixels(dec, s, what):
+    g = s["g"]
+    ref = _oracle_image(s)
+    d = dec.float().cpu()
+    mse = float(((d - ref) ** 2).mean())
+    pool_err = float((torch.nn.functional.avg_pool2d(d, 8) - torch.from_numpy(g["pooled"])).abs().max())
+    crop_mse = float(((d[1, :, 300:332, 40:72] - torch.from_numpy(g["crop1"])) ** 2).mean())
+    print(f"{what}: pixel MSE {mse:.3e} (image std {float(ref.std()):.3f}), pooled max err vs the reference's own image {pool_err:.2e}, crop MSE {crop_mse:.2e}")
+    assert mse <= 1e-4 and crop_mse <= 1e-4, (mse, crop_mse)
+    return mse
+
+
+def _bf16_stats(logits, toks, g, what):
+    """Teacher-forced bf16 statistics against the fixture; logits [T, 2, V], toks [2, T]."""
+    T = g["tokens"].shape[1]
+    sel = torch.from_numpy(g["sel_steps"]).long()
+    vsel = torch.from_numpy(g["vsel"]).long()
+    d = (logits[sel][:, :, vsel] - torch.from_numpy(g["sel_logits"])).abs()                   # [S, 2, 256]
+    top_v = torch.from_numpy(g["top_v"])
+    margin = top_v[..., 0] - top_v[..., 1]                                                     # [T, 2]
+    gold = torch.from_numpy(g["tokens"])
+    agree = (toks == gold).t()                                                                 # [T, 2]
+    late = sel >= 400
+    # the engine's own top-1 value against the reference's top-1 value at EVERY step (sel_logits covers a subset of steps)
+    top_err = (logits.gather(2, torch.from_numpy(g["top_i"][..., :1]).long()).squeeze(-1) - top_v[..., 0]).abs()
+    stats = {"logit_abs_err_max": float(d.max()), "p99": float(np.percentile(d.numpy(), 99)), "p50": float(np.percentile(d.numpy(), 50)),
+             "late_steps_ge_400": {"max": float(d[late].max()), "p99": float(np.percentile(d[late].numpy(), 99)), "p50": float(np.percentile(d[late].numpy(), 50)),
+                                   "agreement": float(agree[400:].float().mean())},
+             "early_steps_lt_400": {"max": float(d[~late].max()), "p99": float(np.percentile(d[~late].numpy(), 99))},
+             "top1_value_err_max_all_steps": float(top_err.max()), "logit_std": float(torch.from_numpy(g["sel_logits"]).std()),
+             "teacher_forced_agreement": float(agree.float().mean()), "margin_median": float(margin.median())}
+    print(f"{what}:", json.dumps(stats))
+    assert stats["logit_abs_err_max"] < BF16_MAX and stats["p99"] < BF16_P99 and stats["top1_value_err_max_all_steps"] < BF16_MAX, stats
+    # the error must not GROW with the context: the late steps (contexts 656-831) inside 1.5x the early ones
+    assert stats["late_steps_ge_400"]["p99"] < 1.5 * stats["early_steps_lt_400"]["p99"] + 0.02, stats
+    err_bound = max(stats["logit_abs_err_max"], stats["top1_value_err_max_all_steps"])
+    flips = (~agree) & (margin > 2 * err_bound)
+    assert not flips.any(), stats
+    assert stats["teacher_forced_agreement"] > 0.90, stats
+    return stats
+
+
+def test_fixture_shape_is_the_real_configuration():
+    g = load_golden("sample_image_fullconfig.npz")
+    assert g["ids"].shape == (4, 256) and g["tokens"].shape == (2, 576) and g["top_v"].shape == (576, 2, 4)
+    assert g["pad"].tolist() == [0, 160, 96, 160]
+    assert float(g["min_margin"]) > 1e-3          # no near tie: free-running fp32 on another summation order cannot legitimately flip a token
+    cfg = R.OracleCfg()
+    assert (cfg.n_layers, cfg.hidden, cfg.inter, cfg.n_heads, cfg.vocab, cfg.img_vocab, cfg.grid, cfg.vq_ch_mult) == (24, 2048, 5632, 16, 102400, 16384, 24, (1, 1, 2, 2, 4))
+
+
+def test_fullconfig_f32_through_t2i_tokens_bit_exact_pixels_within_1e4():
+    """collate -> prefill -> 576 free-running greedy steps -> decode_code, all through ``System.t2i`` in fp32."""
+    from types import SimpleNamespace
+    from plangen_amd.engine import Engine
+    from plangen_amd.system import System
+    s = _setup()
+    g = s["g"]
+    ids, pad, cond, neg = _prompts(g)
+    e = Engine(s["cfg"], dtype="f32", max_rows=4, max_prompt=256, max_new=576, max_images=2)
+    e.load_state_dict(s["W"])
+    try:
+        sysm = System(s["cfg"], e, SimpleNamespace(seed=0, parallel_size=1, cfg_weight=5.0, temperature=0.0, use_teacher_forcing=False,
+                                                   debug_max_seq_len=None, janus_hw=384, neg_prompt="", use_neg_box=False))
+        cfg_ids, cfg_mask = sysm.t2i_infer_collate_batch(cond, neg)
+        assert torch.equal(cfg_ids, ids) and cfg_mask.shape == (4, 256 + 576)
+        dec, mask_image = sysm.t2i(cfg_ids, cfg_mask)
+        toks = sysm.last_generated_tokens.cpu().numpy()
+        assert mask_image is None and dec.shape == (2, 3, 384, 384)
+        bad = np.argwhere(toks != g["tokens"])
+        assert bad.size == 0, f"first mismatch (image, step) {bad[0].tolist()} of {len(bad)}; margin there {float(g['top_v'][bad[0][1], bad[0][0], 0] - g['top_v'][bad[0][1], bad[0][0], 1]):.2e}"
+        _check_pixels(dec, s, "f32 System.t2i")
+        # logits of the same run (second pass, logits requested): error at every stored step incl. the longest contexts
+        e.prefill(cfg_ids, pad, position_mode=0)
+        toks2, logits = e.decode_image_tokens(T=576, cfg_weight=5.0, temperature=0.0, return_logits=True)
+        assert np.array_equal(toks2.cpu().numpy(), g["tokens"])
+        logits = logits.cpu()
+        sel = torch.from_numpy(g["sel_steps"]).long()
+        err = (logits[sel][:, :, torch.from_numpy(g["vsel"]).long()] - torch.from_numpy(g["sel_logits"])).abs()
+        tv, ti = logits.topk(4, dim=-1)
+        terr = (tv - torch.from_numpy(g["top_v"])).abs().max().item()
+        print(f"f32 full configuration: max |logit err| {float(err.max()):.2e} (steps >= 512: {float(err[sel >= 512].max()):.2e}), top-4 value err {terr:.2e}")
+        assert float(err.max()) < F32_LOGIT_TOL and terr < F32_LOGIT_TOL
+        assert np.array_equal(ti[..., 0].numpy(), g["top_i"][..., 0])
+    finally:
+        e.close()
+
+
+def test_fullconfig_bf16_teacher_forced_and_pixels():
+    from plangen_amd.engine import Engine
+    s = _setup()
+    g = s["g"]
+    ids, pad, _, _ = _prompts(g)
+    gold = torch.from_numpy(g["tokens"]).contiguous()
+    e = Engine(s["cfg"], dtype="bf16", max_rows=4, max_prompt=256, max_new=576, max_images=2)
+    e.load_state_dict(s["W"])
+    try:
+        e.prefill(ids, pad, position_mode=0)
+        toks, logits = e.decode_image_tokens(T=576, cfg_weight=5.0, temperature=0.0, force_tokens=gold, return_logits=True)
+        stats = _bf16_stats(logits.cpu(), toks.cpu(), g, "bf16 teacher-forced, 24 layers x L 256 x 576 steps")
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(stats, open(os.path.join(ROOT, "gpurun_out", "fullconfig_bf16_stats.json"), "w"), indent=1)
+        dec = e.vq_decode(gold.to(e.device))
+        _check_pixels(dec, s, "bf16 decode_code on the oracle's tokens")
+    finally:
+        e.close()
+
+
+def _bench_batch(s):
+    """64 pairs shaped like bench.py's batch with the fixture's two pairs as images 62 and 63.  Every uncond row carries the FIXTURE's 96-token
+    negative prompt (bench.synth_prompts' own is 96 tokens too), so the batch takes the same shared-negative-prompt path as the bench:
+    prefilled once, stored once (row 1), aliased by the other 63 uncond rows (checked with the engine's own host helper)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from plangen_amd.engine import Engine
+    g = s["g"]
+    cfg = s["cfg"]
+    b_ids, b_mask = bench.synth_prompts(62, 256, cfg.vocab, cfg.pad_id, seed=0)
+    fx = torch.from_numpy(g["ids"].astype(np.int32))
+    b_ids[1::2] = fx[1]
+    ids = torch.cat([b_ids, fx])
+    pad = [int(256 - m.sum()) for m in b_mask] + [int(p) for p in g["pad"]]
+    assert all(p == 160 for p in pad[1::2]) and Engine.uncond_rows_shared(ids, pad)
+    return ids, pad
+
+
+def test_bench_shape_placement_f32_tokens_of_images_62_63_equal_the_fixture():
+    from plangen_amd.engine import Engine
+    s = _setup()
+    g = s["g"]
+    ids, pad = _bench_batch(s)
+    assert ids.shape == (128, 256)
+    e = Engine(s["cfg"], dtype="f32", max_rows=128, max_prompt=256, max_new=576, max_images=64)     # created exactly like bench.py's engine
+    e.load_state_dict(s["W"])
+    try:
+        e.prefill(ids, pad, position_mode=0)
+        toks = e.decode_image_tokens(T=576, cfg_weight=5.0, temperature=0.0)
+        got = toks.cpu().numpy()
+        assert got.shape == (64, 576)
+        bad = np.argwhere(got[62:] != g["tokens"])
+        assert bad.size == 0, f"first mismatch (image, step) {bad[0].tolist()} of {len(bad)}"
+        # the KV cache rows at the top of the allocation were written where the test thinks: layer 23, last row, last slot is finite and non-zero
+        # layer 23's K block ends 2 x 872 MB below the end of the 41.9 GB cache; its last rows were written where the test thinks:
+        # row 124 (cond, 256 prompt tokens) holds keys up to slot 256 + 574, row 127 (private suffix of an aliased uncond row) up to 96 + 574
+        n = e.debug_read("kcache", 23, 128 * 16 * (256 + 576) * 128, torch.float32).view(128, 16, 256 + 576, 128)
+        for row, slot in ((124, 256 + 574), (127, 96 + 574), (126, 160 + 574)):
+            v = n[row, :, slot]
+            assert torch.isfinite(v).all() and float(v.abs().sum()) > 0, (row, slot)
+            assert float(n[row, :, slot + 1].abs().sum()) == 0, (row, slot)          # nothing beyond the last appended key
+        del n
+        dec = e.vq_decode(toks[62:].contiguous())
+        _check_pixels(dec, s, "f32 bs=64 engine, images 62-63")
+    finally:
+        e.close()
+
+
+def test_bench_shape_placement_bf16_teacher_forced():
+    """The production dtype at the bench shape and depth: images 62-63 teacher-forced on the fixture's tokens (the other 62 images run free)."""
+    from plangen_amd.engine import Engine
+    s = _setup()
+    g = s["g"]
+    ids, pad = _bench_batch(s)
+    e = Engine(s["cfg"], dtype="bf16", max_rows=128, max_prompt=256, max_new=576, max_images=64)
+    e.load_state_dict(s["W"])
+    try:
+        force = torch.zeros((64, 576), dtype=torch.int32)
+        force[62:] = torch.from_numpy(g["tokens"])
+        fmask = torch.ones((64, 576), dtype=torch.uint8)            # edit-region convention (plangen_base.py:593-598): 0 = forced
+        fmask[62:] = 0
+        e.prefill(ids, pad, position_mode=0)
+        toks, logits = e.decode_image_tokens(T=576, cfg_weight=5.0, temperature=0.0, force_tokens=force, force_mask=fmask, return_logits=True)
+        _bf16_stats(logits[:, 62:].cpu(), toks[62:].cpu(), g, "bf16 teacher-forced, images 62-63 of a bs=64 bench-shaped engine")
+    finally:
+        e.close()

@@ -268,7 +268,8 @@ def test_decode_gemm_back_to_back_race_screen(M, N, K, S):
     per-launch checks stayed clean.  Every launch of 4 x 100 must match the 1-deep reference kernel."""
     import ctypes as C
     import os
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_hip.so"))
+    from plangen_amd import _lib
+    lib = _lib.load_diag()          # the production object code + the pg_bench_* harness (libplangen_diag.so)
     lib.pg_bench_skinny_verify.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float)] * 2
     for _ in range(4):
         md, mr = C.c_float(0), C.c_float(0)
@@ -288,7 +289,8 @@ def test_decode_gemm_under_concurrent_memory_load(M, N, K, S, bg_mode):
     LDS-DMA piece).  Before the fix 6 of 6 batches failed here at 32 / 64 / 128 rows; every launch must match the reference kernel."""
     import ctypes as C
     import os
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_hip.so"))
+    from plangen_amd import _lib
+    lib = _lib.load_diag()          # the production object code + the pg_bench_* harness (libplangen_diag.so)
     lib.pg_bench_skinny_verify.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float)] * 2
     for _ in range(3):
         assert lib.pg_bench_background(768, 40, 256, 16, bg_mode) == 0
@@ -337,7 +339,8 @@ def test_hardware_bf16_conversion_equals_software_rne_for_every_float():
     non-NaN input (single and packed form), NaNs stay NaNs."""
     import ctypes as C
     import os
-    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_hip.so"))
+    from plangen_amd import _lib
+    lib = _lib.load_diag()          # the production object code + the pg_bench_* harness (libplangen_diag.so)
     bad, nan_lost = C.c_ulonglong(1), C.c_ulonglong(1)
     assert lib.pg_bench_bf16_cvt_check(C.byref(bad), C.byref(nan_lost)) == 0
     assert bad.value == 0 and nan_lost.value == 0, (bad.value, nan_lost.value)

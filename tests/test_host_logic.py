@@ -85,6 +85,42 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name)
 
 
+def _dynamic_exports(path):
+    import subprocess
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm if os.path.exists(nm) else "nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if l.strip()}
+
+
+def test_product_library_exports_nothing_but_the_header():
+    """libplangen_hip.so exports EXACTLY what include/plangen_hip.h declares (version script plangen_hip.map) -- no
+    microbenchmark / forensics entry points, no C++ launchers; those live in libplangen_diag.so."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "plangen_hip.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(pg_[a-z0-9_]+)\s*\(", hdr))
+    exported = _dynamic_exports(_lib.LIB_PATH)
+    assert exported == declared, exported ^ declared
+    diag = _dynamic_exports(_lib.DIAG_LIB_PATH)
+    assert declared < diag and "pg_diag_set_option" in diag and any(n.startswith("pg_bench_") for n in diag)
+    assert all(n.startswith("pg_") for n in diag), [n for n in diag if not n.startswith("pg_")][:5]
+
+
+def test_product_option_table_is_small_and_has_no_result_changing_switch():
+    """pg_set_option of the product: <= 20 keys, none of the measurement-only switches; they exist only behind pg_diag_set_option."""
+    api = open(os.path.join(ROOT, "plangen_amd", "csrc", "engine_api.hip")).read()
+    body = api[api.index("int pg_set_option("):api.index("int64_t pg_device_bytes(")]
+    keys = re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', body)
+    assert len(keys) == len(set(keys)) and 10 <= len(keys) <= 20, keys
+    diag_src = open(os.path.join(ROOT, "plangen_amd", "csrc", "diag_api.hip")).read()
+    diag_keys = set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', diag_src))
+    for k in ("skip_attn", "attn_variant"):
+        assert k not in keys and k in diag_keys
+    for gone in ("cu_split", "mall_prefetch", "pf_blocks", "attn_pair", "lpt_snake", "gn_fuse"):
+        assert gone not in keys and gone not in diag_keys
+    hdr = open(os.path.join(ROOT, "include", "plangen_hip.h")).read()
+    for k in keys:
+        assert k in hdr, f"option {k} is not documented in include/plangen_hip.h"
+
+
 def test_no_cpu_fallback_without_gpu():
     from plangen_amd.engine import Engine, PlanGenError
     if torch.cuda.is_available():

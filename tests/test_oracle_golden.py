@@ -239,3 +239,31 @@ def test_fullvocab_text_fixture_is_consistent_and_oracle_reproduces_first_steps(
     ids, mask = torch.from_numpy(g["ids"]), torch.from_numpy(g["mask"].astype(np.int32))
     mine = R.generate_text_greedy(W, cfg, R.embed_tokens(W, ids), mask, 3, eos)
     assert np.array_equal(mine.numpy()[:, :3], out[:, :3])
+
+
+def test_fullconfig_fixture_is_consistent():
+    """tests/golden/sample_image_fullconfig.npz (oracle/make_golden.py::golden_full_config): the real configuration at once -- 24 layers x
+    width 2048 x vocabulary 102 400, 2 CFG pairs (cond 256 / 160 tokens, shared 96-token negative prompt, L = 256), all 576 greedy steps,
+    pixels from the reference's own VQ-16.  Host-side consistency only (the transformers-driven loop takes 20 minutes of CPU: the generator
+    asserted oracle == transformers == tokens and oracle VQ == reference VQ before it wrote the file)."""
+    g = load_golden("sample_image_fullconfig.npz")
+    assert g["ids"].shape == (4, 256) and g["tokens"].shape == (2, 576) and g["top_v"].shape == (576, 2, 4) and g["top_i"].shape == (576, 2, 4)
+    assert g["pad"].tolist() == [0, 160, 96, 160]
+    ids, pad = g["ids"], g["pad"]
+    for r in range(4):
+        assert (ids[r, :pad[r]] == R.OracleCfg().pad_id).all() and ids[r, pad[r]] == 1                  # left pad, BOS first
+    assert (ids[1] == ids[3]).all()                                                                    # one shared negative prompt
+    assert np.array_equal(g["top_i"][..., 0].T, g["tokens"])                                           # greedy = first maximum
+    margin = g["top_v"][..., 0] - g["top_v"][..., 1]
+    assert (margin >= 0).all() and abs(float(margin.min()) - float(g["min_margin"])) < 1e-6 and float(g["min_margin"]) > 1e-3
+    sel = g["sel_steps"]
+    assert sel[0] == 0 and (np.diff(sel) > 0).all() and set(range(512, 576)) <= set(sel.tolist()) and g["sel_logits"].shape == (len(sel), 2, 256)
+    # the stored column subset contains each step's winner value wherever the winner is one of the 256 columns
+    vsel = g["vsel"]
+    for si, st in enumerate(sel):
+        for b in range(2):
+            hit = np.nonzero(vsel == g["tokens"][b, st])[0]
+            if hit.size:
+                assert abs(float(g["sel_logits"][si, b, hit[0]]) - float(g["top_v"][st, b, 0])) < 1e-6
+    assert g["pooled"].shape == (2, 3, 48, 48) and g["crop0"].shape == (3, 32, 32) and np.isfinite(g["pooled"]).all()
+    assert 0.05 < float(g["img_std"].min()) and float(np.abs(g["pooled"]).max()) < 4.0

@@ -5,7 +5,7 @@ usage: big_gemm.py M N K [mode=1] [iters=20] [verify=1]            plain A
 mode: 0 = 128x128 kernel, 1 = 256x256 eight-phase (staggered), 2 = 256x256 lock-step"""
 import ctypes as C, os, sys
 import torch  # noqa: F401  (one HIP runtime per process)
-lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 lib.pg_bench_gemm.argtypes = [C.c_int] * 10 + [C.POINTER(C.c_float)] * 2
 a = sys.argv[1:]
 if a[0] == "conv":

@@ -4,7 +4,7 @@ mode bits: 1 three grid barriers, 2 run-ahead weight stream (352 / 464 KiB per C
 import ctypes as C, os, sys
 import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 lib.pg_bench_chain_skeleton.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint)]
 names = {0: "launch only", 1: "3 grid barriers", 2: "weight stream", 4: "gathers + publishes", 3: "barriers + stream", 5: "barriers + gathers/publishes",
          6: "stream + gathers/publishes", 7: "everything"}

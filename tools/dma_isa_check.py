@@ -181,6 +181,8 @@ SPECS = [
     ("gemm256", r"gemm256_kernel", dict(kind="fifo", g=2, need=None, tile_cls=lambda n: n & 3, slot_reuse=lambda c: 8, strict=True,
                                         why="half-tiles retired by vmcnt(8) in the phase before they are read; two barriers per phase")),
     ("gemm", r"gemm_sk4_kernel", dict(kind="sk4")),
+    ("diag_gemm", r"gemm_sk4_kernel", dict(kind="sk4")),
+    ("bench_kernels", r"gemm_sk4_kernel", dict(kind="sk4")),
     ("gemm", r"gemm_big_kernel", dict(kind="big", why="128x128 double buffer: vmcnt(0) + barrier retire tile t+1, a second barrier opens the phase that reads it "
                                       "(round 3; a third LDS slot would halve the kernel's residency, the extra barrier measured free)")),
     ("conv_halo", r"conv3x3_halo_kernelI.*Lb1ELb[01]E", dict(kind="halo_stag", why="production: 4-slot weight ring, W(t+1) retired by vmcnt(2) in phase t and read in phase t+1; "
@@ -188,7 +190,7 @@ SPECS = [
     ("conv_halo", r"conv3x3_halo_kernelI.*Lb0ELb[01]E", dict(kind="halo_lock", why="conv_halo=2 option (lock-step waves): vmcnt(4) + two barriers per K tile")),
     ("bench_kernels", r"dma_order_kernel", dict(kind="probe", why="measurement probe (tools/dma_order_probe.py), not on the product path")),
     ("conv_halo", r"conv3x3_out_halo_kernel", dict(kind="once", why="halo patch staged once per tile (conv_out, 128 -> 3 channels)")),
-    ("llm_kernels", r"weight_prefetch_kernel", dict(kind="sink", why="run-ahead weight prefetcher / background-load stressor: the 1 KiB per-wave LDS sink is written by LDS-DMA and never read")),
+    ("bench_kernels", r"weight_prefetch_kernel", dict(kind="sink", why="background-load stressor of libplangen_diag.so (round 4's run-ahead weight prefetcher): the 1 KiB per-wave LDS sink is written by LDS-DMA and never read")),
     ("chain", r"chain_skel_kernel", dict(kind="probe", why="measured skeleton of the persistent decode chain (tools/chain_skel.py), not on the product path: gathers behind vmcnt(0) + s_barrier, LDS read is a stand-in")),
 ]
 
@@ -200,7 +202,7 @@ def main():
     okc = collections.Counter()          # kernels whose protocol was verified, by spec kind (the machine-readable result)
     report = []
     names = sorted(f[:-4] for f in os.listdir(CSRC) if f.endswith(".hip")
-                   and re.search(r"glds16|global_load_lds", open(os.path.join(CSRC, f)).read()))
+                   and re.search(r"glds16|global_load_lds|gemm_skinny\.h", open(os.path.join(CSRC, f)).read()))      # gemm_skinny.h: the v4 decode GEMM template (gemm.hip = production, diag_gemm.hip = sweep / forensics instantiations)
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=4) as ex:
         compiled = dict(zip(names, ex.map(compile_s, names)))
@@ -302,17 +304,23 @@ def main():
                     okc[spec["kind"]] += 1; report.append(f"ok   {fname}:{short}: patch retired {nbar} barriers before its first read, released by a barrier after the last -- {spec['why']}")
             else:
                 report.append(f"note {fname}:{short}: {spec['kind']} -- {spec['why']}")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sk4_isa_check.py"), _S_PATH["gemm"]], capture_output=True, text=True)
-    last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "no output"
-    report.append("sk4: " + last)
-    if p.returncode != 0:
-        bad += 1
-        report += p.stdout.strip().splitlines()[:5]
-    m = re.match(r"(\d+) .*?(\d+) failed", last)
+    sk4_checked = sk4_failed = 0; sk4_rc = 0
+    for unit in ("gemm", "diag_gemm"):          # production instantiations (libplangen_hip.so) and the diagnostics library's variant table
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sk4_isa_check.py"), _S_PATH[unit]], capture_output=True, text=True)
+        last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "no output"
+        report.append(f"sk4 ({unit}.hip): " + last)
+        if p.returncode != 0:
+            bad += 1; sk4_rc = p.returncode
+            report += p.stdout.strip().splitlines()[:5]
+        m = re.match(r"(\d+) .*?(\d+) failed", last)
+        if m:
+            sk4_checked += int(m.group(1)); sk4_failed += int(m.group(2))
+        else:
+            sk4_checked = -1
     print("\n".join(report))
     # one machine-readable line for tests/test_isa_check.py (wording of the lines above is free to change)
     print("SUMMARY " + json.dumps({"failed": bad, "verified": dict(okc), "notes": sum(1 for l in report if l.startswith("note")),
-                                   "sk4": {"checked": int(m.group(1)) if m else -1, "failed": int(m.group(2)) if m else -1, "rc": p.returncode},
+                                   "sk4": {"checked": sk4_checked, "failed": sk4_failed, "rc": sk4_rc},
                                    "compiler": _compiler_id()[:80]}))
     print(f"{bad} failed")
     return 1 if bad else 0

@@ -3,7 +3,7 @@
 import ctypes as C, os
 import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 lib.pg_bench_dma_order.argtypes = [C.c_int] * 3 + [C.POINTER(C.c_uint)] * 2
 for blocks in (256, 1024):
     for mode in (0, 1, 4, 8, 16, 17, 20):

@@ -4,7 +4,7 @@ usage: sk4_diag.py M reps batches variant [shape ...]   shapes: qkv2 qkv4 o4 gu1
 import ctypes as C, os, sys
 import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 lib.pg_bench_skinny_diag.argtypes = [C.c_int] * 6 + [C.c_uint, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
 M, reps, batches, v = (int(a) for a in sys.argv[1:5])
 dims = {"qkv": (6144, 2048), "o": (2048, 2048), "gu": (11264, 2048), "down": (2048, 5632), "gh": (16384, 2048)}

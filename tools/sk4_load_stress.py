@@ -6,7 +6,7 @@ usage: sk4_load_stress.py M reps [variant ...]      env: BG_MODES="-1 0 2"  BG_B
 import ctypes as C, os, sys
 import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 lib.pg_bench_skinny_verify.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float)] * 2
 M, reps = int(sys.argv[1]), int(sys.argv[2])
 variants = [int(a) for a in sys.argv[3:]] or [2]

@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 import numpy as np
 import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 v, S = int(sys.argv[1]), int(sys.argv[2])
 shape = sys.argv[3] if len(sys.argv) > 3 else "qkv"
 N, K = {"qkv": (6144, 2048), "o": (2048, 2048), "gu": (11264, 2048), "down": (2048, 5632)}[shape]

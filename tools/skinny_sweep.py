@@ -7,7 +7,7 @@ import sys
 import torch  # noqa: F401  (HIP runtime load order)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 lib.pg_bench_skinny.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_float)]
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 BK = {0: 128, 1: 128, 2: 256, 3: 256, 4: 256, 5: 128, 6: 256, 7: 128, 8: 128, 9: 128, 10: 256, 11: 64, 20: 128, 21: 128, 22: 128, 23: 128, 24: 128, 25: 128, 30: 128, 31: 128, 32: 128, 33: 128, 34: 128, 35: 128, 36: 128, 37: 128, 38: 128, 26: 128, 27: 128, 40: 64, 50: 128, 51: 128, 52: 128, 53: 128, 54: 128, 60: 128, 61: 128, 62: 128}

@@ -2,7 +2,7 @@
 """Pure streaming-read calibration on the GPU box (ceiling for the HBM-bound kernels)."""
 import ctypes as C, os
 import torch  # noqa: F401
-lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 lib.pg_bench_stream.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
 for mb in (64, 411, 1024):
     for blocks in (1024, 2048, 4096, 8192):

@@ -3,7 +3,7 @@
 import ctypes as C, os
 import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 lib.pg_bench_stream.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
 for mb in (8.4, 23.1, 25.2, 46.1, 67.1, 256.0):
     for nt in (0, 1):

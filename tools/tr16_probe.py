@@ -3,7 +3,7 @@
 import ctypes as C, os
 import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_hip.so"))
+lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
 def run(addrs, title):
     a = (C.c_int * 64)(*addrs); o = (C.c_ushort * 256)()
     rc = lib.pg_bench_tr16_probe(a, o)
