@@ -38,10 +38,16 @@ __device__ __forceinline__ void sum_slabs(const float* __restrict__ p, long slab
 // after the barrier, in the loop's own kv[] / vv[] registers (no double buffer, still 4 waves per SIMD); the append is ONE
 // 8-byte-per-lane store instruction per block, issued after the barrier.  Loop 1800 -> 1783 ms at bs=64.
 template <typename T, int UN, int NW, int ABL = 0>      // ABL (timing ablations, WRONG results): 1 no K/V append store, 2 no slab / cos / sin loads, 4 no merge epilogue
-__global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float* __restrict__ qkv, int S, long slab,
-                                                              T* __restrict__ obuf, T* __restrict__ kc, T* __restrict__ vc,
+// Argument order (round 5): gfx950 preloads the first 14 kernarg dwords into SGPRs at wave launch (-amdgpu-kernarg-preload-count); the rest
+// arrive through an s_load that misses every cache (the host wrote the kernarg block for this launch).  The first 56 bytes are therefore
+// exactly what the FIRST K/V chunk's addresses need -- row order, lengths, step counter, cache bases, geometry, shared-prompt alias -- and
+// what the RoPE prologue needs (slabs, cos / sin, positions, output) comes behind them, under the chunk's flight.
+__global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const int32_t* __restrict__ row_order, const int32_t* __restrict__ len_p,
+                                                              const int32_t* __restrict__ n_dec_p, T* __restrict__ kc, T* __restrict__ vc,
+                                                              int nh, int slots, int shared_len, int shared_row,
+                                                              const float* __restrict__ qkv, long slab, T* __restrict__ obuf,
                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                              SeqState st, int nh, int slots, int max_pos, float scale) {
+                                                              const int32_t* __restrict__ pos_off_p, int S, int max_pos, float scale) {
     constexpr int EPV = ET<T>::EPV, LPK = 128 / EPV, KPI = 64 / LPK, NST = NW * KPI;
     __shared__ float s_o[NST][128];
     __shared__ float s_m[NST], s_l[NST];
@@ -57,16 +63,16 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
 #pragma unroll 1
     for (int it = 0; it < NIT; ++it) {
     const int yi = it == 0 ? (int)blockIdx.y : (int)(2 * gridDim.y - 1 - blockIdx.y);
-    const int row = st.row_order ? st.row_order[yi] : yi;
+    const int row = row_order ? row_order[yi] : yi;
     const int grp = l / LPK, lk = l % LPK;
-    const int slot = st.len[row] + *st.n_dec;
+    const int slot = len_p[row] + *n_dec_p;
     const int nprev = slot < slots ? slot : slots - 1;
     const int HD = nh * 128;
     const long cbase = ((long)row * nh + head) * slots * 128;
     constexpr int KPW = KPI * UN;
-    const bool sh = st.shared_len > 0 && (row & 1);
-    const int kstart = sh ? (st.shared_len < nprev ? st.shared_len : nprev) : 0;
-    const long sbase = ((long)st.shared_row * nh + head) * (long)slots * 128 + lk * EPV;
+    const bool sh = shared_len > 0 && (row & 1);
+    const int kstart = sh ? (shared_len < nprev ? shared_len : nprev) : 0;
+    const long sbase = ((long)shared_row * nh + head) * (long)slots * 128 + lk * EPV;
     const T* const kpriv = kc + cbase + lk * EPV; const T* const vpriv = vc + cbase + lk * EPV;
     const T* const kshr = kc + sbase; const T* const vshr = vc + sbase;
 
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_fused_kernel(const float*
     // values are waited for with the K/V chunk still in flight behind them.
     const int o6[6] = {0, 64, HD, HD + 64, 2 * HD, 2 * HD + 64};
     float t4[4][6], cs = 0.f, sn = 0.f;
-    int pos = st.pos_off[row] + slot;
+    int pos = pos_off_p[row] + slot;
     if (pos >= max_pos) pos = max_pos - 1;
     const float* const qrow = qkv + (long)row * 3 * HD + head * 128 + (tid & 63);
     if (tid < 64) {

@@ -8,7 +8,7 @@
 template <typename T>
 static bool diag_attn_decode_t(hipStream_t s, const float* qkv, int S, long slab, T* obuf, T* kc, T* vc, const float* cos_t, const float* sin_t,
                                const SeqState& st, int M, int nh, int slots, int max_pos, float scale) {
-#define ATT_LAUNCH(U, W, A) hipLaunchKernelGGL((attn_decode_fused_kernel<T, U, W, A>), dim3(nh, M), dim3(64 * W), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, nh, slots, max_pos, scale)
+#define ATT_LAUNCH(U, W, A) hipLaunchKernelGGL((attn_decode_fused_kernel<T, U, W, A>), dim3(nh, M), dim3(64 * W), 0, s, st.row_order, st.len, st.n_dec, kc, vc, nh, slots, st.shared_len, st.shared_row, qkv, slab, obuf, cos_t, sin_t, st.pos_off, S, max_pos, scale)
     const int av = pg_tune->attn_variant;
     const bool small = (M * nh <= 512 && pg_tune->attn_waves != 4) || pg_tune->attn_waves == 8;
     if (av == 100) { if (small) ATT_LAUNCH(7, 8, 0); else ATT_LAUNCH(7, 4, 0); return true; }

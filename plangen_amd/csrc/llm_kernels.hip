@@ -27,11 +27,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(float* __restrict__ x, con
 }
 // 512 threads per row (H = 2048: one f32x4 per thread and slab): twice the waves issue the row's loads
 template <typename T, int SB>
-__global__ __launch_bounds__(512) void rmsnorm512_kernel(float* __restrict__ x, const float* __restrict__ partial,
-                                                        int S, long slab, const T* __restrict__ w,
-                                                        T* __restrict__ xn, int H, float eps, int32_t* __restrict__ advance) {
+__global__ __launch_bounds__(512) void rmsnorm512_kernel(float* __restrict__ x, const float* __restrict__ partial, const T* __restrict__ w,
+                                                        T* __restrict__ xn, int32_t* __restrict__ advance, int S, int slab, int H, float eps) {
+    // 5 pointers + 4 x 32 bits = 56 bytes: the whole kernarg block is preloaded into SGPRs at wave launch (see attn_decode.h); slab (elements
+    // of one split-K slab, M x N <= 2^31) travels as int for that
     __shared__ float red[8];
-    rmsnorm_row<T, 1, false, SB, 512>(blockIdx.x, x, partial, S, slab, w, xn, H, eps, red);
+    rmsnorm_row<T, 1, false, SB, 512>(blockIdx.x, x, partial, S, (long)slab, w, xn, H, eps, red);
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
 }
 template <typename T>
@@ -39,8 +40,8 @@ void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long s
                     int M, int H, float eps, int32_t* advance) {
     if (M <= 0) return;
     if (H == 2048) {                               // every row count (the reduction order must not depend on M: sharded == unsharded tokens); decode loop -8 ms at bs=64, -7 ms at bs=8 vs 256 threads per row
-        if (S > 4) hipLaunchKernelGGL((rmsnorm512_kernel<T, 8>), dim3(M), dim3(512), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
-        else hipLaunchKernelGGL((rmsnorm512_kernel<T, 4>), dim3(M), dim3(512), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
+        if (S > 4) hipLaunchKernelGGL((rmsnorm512_kernel<T, 8>), dim3(M), dim3(512), 0, s, x, partial, w, xn, advance, S, (int)slab, H, eps);
+        else hipLaunchKernelGGL((rmsnorm512_kernel<T, 4>), dim3(M), dim3(512), 0, s, x, partial, w, xn, advance, S, (int)slab, H, eps);
         return;
     }
     if (H <= 1024) hipLaunchKernelGGL((rmsnorm_kernel<T, 1>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
@@ -283,7 +284,7 @@ void launch_attn_decode_fused(hipStream_t s, const float* qkv, int S, long slab,
     // instantiated in libplangen_hip.so; the older non-pipelined kernel and the timing ablations live in libplangen_diag.so (diag_attn.hip),
     // which registers itself in PgTune::diag.
     if (pg_tune->diag && pg_tune->diag->attn_decode && pg_tune->diag->attn_decode(s, std::is_same<T, bf16>::value, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, M, nh, slots, max_pos, scale)) return;
-#define ATT_LAUNCH(U, W, A) hipLaunchKernelGGL((attn_decode_fused_kernel<T, U, W, A>), dim3(nh, M), dim3(64 * W), 0, s, qkv, S, slab, obuf, kc, vc, cos_t, sin_t, st, nh, slots, max_pos, scale)
+#define ATT_LAUNCH(U, W, A) hipLaunchKernelGGL((attn_decode_fused_kernel<T, U, W, A>), dim3(nh, M), dim3(64 * W), 0, s, st.row_order, st.len, st.n_dec, kc, vc, nh, slots, st.shared_len, st.shared_row, qkv, slab, obuf, cos_t, sin_t, st.pos_off, S, max_pos, scale)
     const bool small = (M * nh <= 512 && pg_tune->attn_waves != 4) || pg_tune->attn_waves == 8;
     if (small) ATT_LAUNCH(5, 8, 16);
     else ATT_LAUNCH(6, 4, 16);

@@ -30,7 +30,8 @@ pytestmark = pytest.mark.gpu
 
 _S = {}
 F32_LOGIT_TOL = 5e-3          # 24 layers of fp32 with a different summation order (measured: see the printed value)
-BF16_MAX, BF16_P99 = 0.45, 0.30      # teacher-forced |logit error| bounds, 1.5x the values measured on MI355X (printed by the test; round 5)
+BF16_MAX, BF16_P99 = 0.43, 0.25      # teacher-forced |logit error| bounds = 1.5x the values measured on MI355X in round 5: 4-row engine max 0.265 / p99 0.155 / p50 0.039,
+                                      # images 62-63 of the bs=64 engine max 0.285 / p99 0.155 (logit std 2.37; steps >= 400 are no worse than the early ones: p99 0.148-0.150)
 
 
 def _setup():
@@ -74,7 +75,9 @@ def _check_pixels(dec, s, what):
     pool_err = float((torch.nn.functional.avg_pool2d(d, 8) - torch.from_numpy(g["pooled"])).abs().max())
     crop_mse = float(((d[1, :, 300:332, 40:72] - torch.from_numpy(g["crop1"])) ** 2).mean())
     print(f"{what}: pixel MSE {mse:.3e} (image std {float(ref.std()):.3f}), pooled max err vs the reference's own image {pool_err:.2e}, crop MSE {crop_mse:.2e}")
-    assert mse <= 1e-4 and crop_mse <= 1e-4, (mse, crop_mse)
+    # north_star's bound is the MSE over the decoded tensor; a 32 x 32 crop against the reference's own pixels is a local sample of it (bf16 measured
+    # 9.6e-5 on this crop at a whole-image MSE of 5.5e-5): bounded at 3x the budget so a local blow-up still fails
+    assert mse <= 1e-4 and crop_mse <= 3e-4, (mse, crop_mse)
     return mse
 
 

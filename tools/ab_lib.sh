@@ -6,7 +6,7 @@ cp $L/libplangen_hip.so /tmp/new.so; cp $L/libplangen_hip_old.so.bin /tmp/old.so
 for r in $(seq 1 ${1:-2}); do
   for v in new old; do
     cp /tmp/$v.so $L/libplangen_hip.so
-    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ${BATCH:+--batch $BATCH} 2>/dev/null | python -c "
+    python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-rccl-selftest ${BATCH:+--batch $BATCH} 2>/dev/null | python -c "
 import json,sys
 j=json.loads(sys.stdin.readline()); print('%-4s img/s %.2f  step %.1f ms  loop %.1f  prefill %.1f  vq %.1f' % ('$v', j['value'], j['ms_per_step'], j['last_step_ms']['decode_loop'], j['last_step_ms']['prefill'], j['last_step_ms']['vq_decode']))"
   done

@@ -24,6 +24,8 @@ import os, re, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "plangen_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+# the code-generation flags of plangen_amd/csrc/Makefile (the listing checked here must be the code that ships)
+ISA_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 _S_PATH = {}
 
 
@@ -41,7 +43,7 @@ def compile_s(name):
     import hashlib, tempfile
     src = os.path.join(CSRC, name + ".hip")
     deps = [src] + sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h"))
-    hsh = hashlib.sha256(_compiler_id().encode())
+    hsh = hashlib.sha256((_compiler_id() + " ".join(ISA_FLAGS)).encode())
     for d in deps:
         hsh.update(open(d, "rb").read())
     out = os.path.join(tempfile.gettempdir(), f"dma_isa_{os.getuid()}")
@@ -50,8 +52,7 @@ def compile_s(name):
     if not os.path.exists(dst):
         fd, tmp = tempfile.mkstemp(suffix=".s", dir=out)
         os.close(fd)
-        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
-                               src, "-I", CSRC, "-o", tmp], stderr=subprocess.DEVNULL)
+        subprocess.check_call([HIPCC, *ISA_FLAGS, "-S", "--cuda-device-only", src, "-I", CSRC, "-o", tmp], stderr=subprocess.DEVNULL)
         os.replace(tmp, dst)
         for f in os.listdir(out):                                  # drop older listings of the same source
             if f.startswith(name + ".") and f.endswith(".s") and os.path.join(out, f) != dst:

@@ -14,7 +14,7 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/sk4_check.s"
 if len(sys.argv) < 2:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-S", "--cuda-device-only",
                            os.path.join(ROOT, "plangen_amd/csrc/gemm.hip"), "-I", os.path.join(ROOT, "plangen_amd/csrc"), "-o", path],
                           stderr=subprocess.DEVNULL)
 lines = open(path).read().splitlines()
