@@ -564,3 +564,80 @@ extern "C" int pg_bench_bf16_cvt_check(unsigned long long* mismatches, unsigned 
     if (nan_lost) *nan_lost = h[1];
     return rc;
 }
+
+
+// ------------------------------------------------------------------------------- fused-norm producer (round 5 experiment)
+// Pair A: production split-K GEMM (tiled weights) + rmsnorm512 (reduce + residual + norm).  B: the EPI 5 producer alone (reduce + residual +
+// bf16(x w) + per-row sums of squares in its tail).  Times both over rotating weights and checks B against A's arithmetic: x_new bit-identical,
+// xw == bf16(x_new * w), ssq within fixed-point resolution of sum x_new^2.
+__global__ void fused_check_kernel(const float* xa, const float* xb, const bf16* xw, const bf16* w, const unsigned long long* ssq, int M, int N, unsigned* bad) {
+    const int m = blockIdx.x;
+    double q = 0;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const float a = xa[(long)m * N + n], b = xb[(long)m * N + n];
+        if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(bad, 1u);
+        const uint32_t want = f32_to_bf16_bits(ET<bf16>::ld(w + n) * b);
+        if (want != (uint32_t)(*(const unsigned short*)(xw + (long)m * N + n))) atomicAdd(bad + 1, 1u);
+        q += (double)b * b;
+    }
+    __shared__ double sq[256];
+    sq[threadIdx.x] = q; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sq[threadIdx.x] += sq[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        const double got = (double)ssq[m] / 268435456.0;
+        if (fabs(got - sq[0]) > 1e-5 * sq[0] + 1e-6) atomicAdd(bad + 2, 1u);
+    }
+}
+extern "C" int pg_bench_fused_norm(int M, int N, int K, int S, int iters, float* us_pair, float* us_gemm, float* us_fused, unsigned* bad_out) {
+    const long wbytes = (long)N * K * 2;
+    int nbuf = (int)((600L << 20) / wbytes) + 1; if (nbuf > 32) nbuf = 32; if (nbuf < 2) nbuf = 2;
+    std::vector<bf16*> Ws(nbuf);
+    bf16* Wrow; hipMalloc((void**)&Wrow, wbytes);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, Wrow, (long)N * K, 7u);
+    for (auto& p : Ws) { if (hipMalloc((void**)&p, wbytes) != hipSuccess) return -2; launch_tile_weights(0, Wrow, p, N, K); }
+    bf16 *x, *wn, *xn, *xw; float *slabs, *xa, *xb, *x0; unsigned long long* ssq; unsigned *ticket, *bad; SkFuse* site;
+    hipMalloc((void**)&x, (long)M * K * 2); hipMalloc((void**)&wn, N * 2); hipMalloc((void**)&xn, (long)M * N * 2); hipMalloc((void**)&xw, (long)M * N * 2);
+    hipMalloc((void**)&slabs, (long)S * M * N * 4); hipMalloc((void**)&xa, (long)M * N * 4); hipMalloc((void**)&xb, (long)M * N * 4); hipMalloc((void**)&x0, (long)M * N * 4);
+    hipMalloc((void**)&ssq, M * 8); hipMalloc((void**)&ticket, 4096 * 4); hipMalloc((void**)&bad, 16); hipMalloc((void**)&site, sizeof(SkFuse));
+    hipMemset(ticket, 0, 4096 * 4); hipMemset(bad, 0, 16);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(256), dim3(256), 0, 0, x, (long)M * K, 3u);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(16), dim3(256), 0, 0, wn, (long)N, 9u);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(256), dim3(256), 0, 0, (bf16*)x0, (long)M * N * 2, 13u);      // fp32 residual: arbitrary finite bit patterns of two bf16 halves
+    SkFuse hs{xb, wn, xw, ssq, ticket, nullptr};
+    hipMemcpy(site, &hs, sizeof(hs), hipMemcpyHostToDevice);
+    hipStream_t s; hipStreamCreate(&s);
+    PgTune tune; const PgTune* const saved = pg_tune; pg_tune = &tune;
+    int rc = 0;
+    // ---- correctness: 20 rounds, fresh residual each
+    for (int r = 0; r < 20 && rc == 0; ++r) {
+        hipMemcpyAsync(xa, x0, (long)M * N * 4, hipMemcpyDeviceToDevice, s); hipMemcpyAsync(xb, x0, (long)M * N * 4, hipMemcpyDeviceToDevice, s);
+        hipMemsetAsync(ssq, 0, M * 8, s);
+        if (!launch_gemm_skinny_tiled_only(s, x, Ws[r % nbuf], slabs, M, N, K, S)) { rc = -1; break; }
+        launch_rmsnorm<bf16>(s, xa, slabs, S, (long)M * N, wn, xn, M, N, 1e-6f);
+        hipMemsetAsync(slabs, 0xff, (long)S * M * N * 4, s);
+        if (!launch_gemm_skinny_fused_norm(s, x, Ws[r % nbuf], slabs, M, N, K, S, site)) { rc = -1; break; }
+        hipLaunchKernelGGL(fused_check_kernel, dim3(M), dim3(256), 0, s, xa, xb, xw, wn, ssq, M, N, bad);
+    }
+    hipStreamSynchronize(s);
+    hipMemcpy(bad_out, bad, 12, hipMemcpyDeviceToHost);
+    // ---- timing
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    auto time_it = [&](int mode, float* out) {
+        for (int it = -5; it < iters; ++it) {
+            if (it == 0) hipEventRecord(e0, s);
+            bf16* Wt = Ws[(it + 5) % nbuf];
+            if (mode == 0) { launch_gemm_skinny_tiled_only(s, x, Wt, slabs, M, N, K, S); launch_rmsnorm<bf16>(s, xa, slabs, S, (long)M * N, wn, xn, M, N, 1e-6f); }
+            else if (mode == 1) launch_gemm_skinny_tiled_only(s, x, Wt, slabs, M, N, K, S);
+            else launch_gemm_skinny_fused_norm(s, x, Wt, slabs, M, N, K, S, site);
+        }
+        hipEventRecord(e1, s); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); *out = ms * 1000.f / iters;
+    };
+    if (rc == 0) { time_it(0, us_pair); time_it(1, us_gemm); time_it(2, us_fused); }
+    if (hipGetLastError() != hipSuccess) rc = -2;
+    pg_tune = saved;
+    for (auto p : Ws) hipFree(p);
+    hipFree(Wrow); hipFree(x); hipFree(wn); hipFree(xn); hipFree(xw); hipFree(slabs); hipFree(xa); hipFree(xb); hipFree(x0); hipFree(ssq); hipFree(ticket); hipFree(bad); hipFree(site);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    return rc;
+}

@@ -9,6 +9,8 @@ void launch_gemm_skinny_v1(hipStream_t s, const bf16* x, const bf16* W, float* o
 bool launch_gemm_skinny_tiled_only(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S);
 // diag_gemm.hip: variant table for the microbenchmarks; returns BK (0 = unsupported)
 int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S);
+struct SkFuse;
+bool launch_gemm_skinny_fused_norm(hipStream_t s, const bf16* x, const bf16* Wt, float* slabs, int M, int N, int K, int S, const SkFuse* site_dev);
 // diag_attn.hip: PgDiagHooks::attn_decode -- attn_variant 100 = the round-2 non-pipelined 7-deep kernel, 101-107 = timing ablations of the
 // production kernel (results wrong by construction); anything else returns false (production kernel runs)
 bool diag_attn_decode(hipStream_t s, bool is_bf16, const float* qkv, int S, long slab, void* obuf, void* kc, void* vc, const float* cos_t, const float* sin_t,

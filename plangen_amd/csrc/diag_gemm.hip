@@ -63,3 +63,11 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         default: return 0;
     }
 }
+
+// Round 5 experiment: the split-K producer with the consumer norm's reduction in its tail (gemm_skinny.h, EPI 5), same block
+// shapes as the production o_proj / down_proj dispatch (sk4_prod: 64-row blocks above 16 rows, 16-row blocks up to 16).
+bool launch_gemm_skinny_fused_norm(hipStream_t s, const bf16* x, const bf16* Wt, float* slabs, int M, int N, int K, int S, const SkFuse* site_dev) {
+    if (M > 128 || !site_dev) return false;
+    if (M > 16) return sk4_nck<4, 4, 3, 5, 2, 64>(s, x, Wt, slabs, M, N, K, S, site_dev);
+    return sk4_nck<1, 5, 3, 5, 4, 64>(s, x, Wt, slabs, M, N, K, S, site_dev);
+}

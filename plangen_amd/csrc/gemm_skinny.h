@@ -441,6 +441,82 @@ template <int C, int NCK, int XD, int WD, int MT, class F> __device__ __forceinl
     if constexpr (C < NCK) { f(std::integral_constant<int, C>{}); sk4_static_for<C + 1, NCK, XD, WD, MT>(f); }
 }
 
+// ---- EPI 5 (round 5 experiment): split-K producer with the consumer norm's reduction folded into its TAIL.
+// Every split block stores its slab tile write-through, waits for the acknowledgements and takes a ticket of its (row block, column block)
+// tile; the block that draws the LAST ticket re-reads all S slab tiles (fixed order s = 0 .. S-1, loads that bypass this XCD's L2: the other
+// splits ran on other XCDs), adds the residual and writes x, xw = bf16(x . w_norm) -- the consumer GEMM's A operand WITHOUT the 1/rms, which
+// commutes with the GEMM and is applied in the consumer's epilogue -- and adds the tile's per-row sums of squares to ssq[row] as 2^-28
+// fixed point (integer atomics: the order of arrival cannot change the sum).  No grid barrier, no polling: the other S - 1 blocks exit.
+struct SkFuse {                        // device-resident, one per norm site
+    float* x;                          // residual stream [M][N] fp32, in / out
+    const bf16* w;                     // the consumer norm's weight [N]
+    bf16* xw;                          // out [M][N]: bf16(x_new * w)
+    unsigned long long* ssq;           // [M] += sum_n x_new^2 * 2^28 (zeroed once per decode step)
+    unsigned* ticket;                  // [row blocks][column blocks], self-resetting (atomicInc wraps at S - 1)
+    int32_t* advance;                  // optional decode step counter, bumped by tile (0, 0)'s finisher
+};
+#define SK_SSQ_SCALE 268435456.f       // 2^28
+__device__ __forceinline__ f32x4 sk_load_sc1(const float* p) {          // device-scope load: never served from this XCD's (non-coherent) L2
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int MTW>
+__device__ __forceinline__ void sk4_finish_tile(const SkFuse* __restrict__ fsp, const float* __restrict__ slabs, int S, int M, int N, int mb, int ncol0,
+                                                int g, int lr, int w, int tid, float* red /* >= 4 * MTW * 16 floats of LDS */) {
+    const SkFuse fs = *fsp;
+    const int n = ncol0 + g * 4;
+    f32x4 v[MTW]; float ss[MTW];
+    const u32x2 wv = *(const u32x2*)(fs.w + (n < N ? n : 0));
+    long o[MTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int m = mb + mt * 16 + lr, mc = m < M ? m : M - 1;
+        o[mt] = (long)mc * N + (n < N ? n : 0);
+        v[mt] = *(const f32x4*)(fs.x + o[mt]);                          // x was written by an earlier kernel: ordinary load
+    }
+    // every slab request of the tile (MTW m-tiles x up to 4 slabs per pass) in flight together: ONE memory round trip per pass, added in slab order
+    for (int s0 = 0; s0 < S; s0 += 4) {
+        f32x4 t[MTW][4];
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[mt][u] = sk_load_sc1(slabs + (long)(s0 + u < S ? s0 + u : S - 1) * M * N + o[mt]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { asm volatile("" : "+v"(t[mt][u])); if (s0 + u < S) v[mt] += t[mt][u]; }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int m = mb + mt * 16 + lr;
+        float q = v[mt][0] * v[mt][0] + v[mt][1] * v[mt][1] + v[mt][2] * v[mt][2] + v[mt][3] * v[mt][3];
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);         // the n-tile's 16 columns (4 lane groups)
+        ss[mt] = q;
+        if (m < M && n < N) {
+            const long o = (long)m * N + n;
+            *(f32x4*)(fs.x + o) = v[mt];
+            u32x2 ov;
+            ov.x = pack_bf16x2(bf16_lo(wv.x) * v[mt][0], bf16_hi(wv.x) * v[mt][1]);
+            ov.y = pack_bf16x2(bf16_lo(wv.y) * v[mt][2], bf16_hi(wv.y) * v[mt][3]);
+            *(u32x2*)(fs.xw + o) = ov;
+        }
+    }
+    // the block's four n-tile waves -> one fixed-point atomic per row
+    if (g == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) red[(w & 3) * (MTW * 16) + mt * 16 + lr] = ss[mt];
+    }
+    __syncthreads();
+    if (tid < MTW * 16) {
+        const int m = mb + tid;
+        const float q = (red[tid] + red[MTW * 16 + tid]) + (red[2 * MTW * 16 + tid] + red[3 * MTW * 16 + tid]);
+        if (m < M) atomicAdd(fs.ssq + m, (unsigned long long)__float2ull_rn(q * SK_SSQ_SCALE));
+    }
+    if (fs.advance && tid == 0 && blockIdx.x == 0 && blockIdx.z == 0) *fs.advance += 1;
+}
+
 // MS = 2: 8 waves per block, wave w = (n-tile w & 3, row half w >> 2): two waves per SIMD, so one wave's LDS fragment
 // reads run under the other's MFMAs (measured with 4 lock-stepped waves: reads and MFMAs of a chunk serialise,
 // ~1050 cycles per chunk instead of ~550).  Both row halves load the same W fragments (second one hits L1/L2).
@@ -524,31 +600,45 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
     if constexpr (EPI == 3) sk4_store_swiglu_direct<MTW>(acc, (bf16*)out, M, N / 2, mb, ntile, g, lr);
     else if constexpr (EPI == 2) sk4_store_direct<MTW>(acc, out + (long)split * M * N, M, N, mb, ntile * 16, g, lr);
     else if constexpr (EPI == 4) sk4_store_direct<MTW, true>(acc, out + (long)split * M * N, M, N, mb, ntile * 16, g, lr);
+    else if constexpr (EPI == 5) {
+        static_assert(EPI != 5 || MS == 1, "fused-norm producer: MS = 1");
+        const int S = gridDim.y;
+        const SkFuse* fsp = (const SkFuse*)prof;                          // EPI 5: the last kernel argument is the norm site
+        sk4_store_direct<MTW, true>(acc, out + (long)split * M * N, M, N, mb, ntile * 16, g, lr);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's write-through stores are acknowledged
+        __syncthreads();                                                  // ... and every wave's of the block
+        unsigned* s_old = (unsigned*)smem;                               // the x ring is dead: every wave is past its last LDS read (barrier above)
+        if (tid == 0) *s_old = S > 1 ? atomicInc(fsp->ticket + blockIdx.z * gridDim.x + blockIdx.x, (unsigned)(S - 1)) : 0u;
+        __syncthreads();
+        if (*s_old != (unsigned)(S - 1)) return;
+        __syncthreads();                                                  // s_old read by everyone before red[] (same LDS) is written
+        sk4_finish_tile<MTW>(fsp, out, S, M, N, mb, ntile * 16, g, lr, w, tid, (float*)smem);
+    }
     else if constexpr (EPI == 1) { static_assert(EPI != 1 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_swiglu<MT, 4>(smem, acc, (bf16*)out, M, N / 2, mbase, blockIdx.x, w, g, lr, tid); }
     else { static_assert(EPI != 0 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_tile<MT, 4>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid); }
     if constexpr (PROF) { if (pw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); } }
 }
 extern unsigned long long* g_sk4_prof;          // stamp buffer of the PROF instantiations (libplangen_diag.so: tools/sk4_profile.py); null in production
 template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
-static void launch_sk4(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+static void launch_sk4(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S, const void* tail = nullptr) {      // tail: EPI 5's SkFuse site
     constexpr int XL = XD * MT * 16 * 256 + ((ABL & 512) ? 4096 * MS : 0), TL = MT * 16 * (4 * 16 + 4) * 4;
     constexpr int LDS = XL > TL ? XL : TL;
     auto kfn = gemm_sk4_kernel<MT, NCK, XD, WD, EPI, OCC, ABL, MS>;
     (void)PG_DYN_LDS(kfn, LDS);
     dim3 grid((N + 63) / 64, S, (M + MT * 16 - 1) / (MT * 16)), block(256 * MS);
-    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, Wt, out, M, N, K, g_sk4_prof);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, Wt, out, M, N, K, tail ? (unsigned long long*)tail : g_sk4_prof);
 }
 template <int MT, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
-static bool sk4_nck(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+static bool sk4_nck(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S, const void* tail = nullptr) {
     const int nck = K / SK_BK / S;
     if (nck * S * SK_BK != K || (N & 15)) return false;
     switch (nck) {
-        case 2: launch_sk4<MT, 2, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
-        case 4: launch_sk4<MT, 4, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
-        case 8: launch_sk4<MT, 8, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
-        case 11: launch_sk4<MT, 11, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
-        case 16: launch_sk4<MT, 16, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
-        case 22: launch_sk4<MT, 22, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S); return true;
+        case 2: launch_sk4<MT, 2, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S, tail); return true;
+        case 4: launch_sk4<MT, 4, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S, tail); return true;
+        case 8: launch_sk4<MT, 8, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S, tail); return true;
+        case 11: launch_sk4<MT, 11, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S, tail); return true;
+        case 16: launch_sk4<MT, 16, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S, tail); return true;
+        case 22: launch_sk4<MT, 22, XD, WD, EPI, OCC, ABL, MS>(s, x, Wt, out, M, N, K, S, tail); return true;
         default: return false;
     }
 }
