@@ -344,3 +344,32 @@ def test_hardware_bf16_conversion_equals_software_rne_for_every_float():
     bad, nan_lost = C.c_ulonglong(1), C.c_ulonglong(1)
     assert lib.pg_bench_bf16_cvt_check(C.byref(bad), C.byref(nan_lost)) == 0
     assert bad.value == 0 and nan_lost.value == 0, (bad.value, nan_lost.value)
+
+
+@pytest.mark.parametrize("mode", [4, 5, 6, 1])
+@pytest.mark.parametrize("M,N,K", [(13285, 2048, 2048), (6600, 2048, 5632), (6100, 6144, 2048)])
+def test_gemm256_tile_heights_are_bit_identical_to_the_128_tile_kernel(M, N, K, mode):
+    """Round 5: gemm256_kernel's tile height is chosen per launch (256 / 224 / 192 rows = `gemm256` 4 / 5 / 6; 1 = pick_tile_height()).
+    Same K order in every form: each of 3 launches must equal the 128x128 kernel bit for bit (ragged last tile rows included)."""
+    import ctypes as C
+    from plangen_amd import _lib
+    lib = _lib.load_diag()
+    lib.pg_bench_gemm.argtypes = [C.c_int] * 10 + [C.POINTER(C.c_float)] * 2
+    us, md = C.c_float(0), C.c_float(-1)
+    assert lib.pg_bench_gemm(M, N, K, 0, 0, 0, 0, mode, 2, 3, C.byref(us), C.byref(md)) == 0
+    assert md.value == 0.0, md.value
+
+
+@pytest.mark.parametrize("M,N,K,S", [(128, 2048, 2048, 4), (128, 2048, 5632, 4), (64, 2048, 5632, 11), (16, 2048, 2048, 4)])
+def test_fused_norm_producer_experiment_matches_the_production_pair(M, N, K, S):
+    """Round 5 experiment kept in libplangen_diag.so (profiles/r05_b, measured slower and NOT integrated): the split-K producer whose last-arrival
+    block reduces the slabs, adds the residual and emits bf16(x w) + fixed-point row sums of squares.  Its cross-XCD publication (write-through
+    stores, device-scope ticket, L2-bypassing reloads) must reproduce the production GEMM + rmsnorm512 arithmetic: x bit-identical, xw and ssq exact."""
+    import ctypes as C
+    from plangen_amd import _lib
+    lib = _lib.load_diag()
+    lib.pg_bench_fused_norm.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_float)] * 3 + [C.POINTER(C.c_uint)]
+    a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+    bad = (C.c_uint * 4)()
+    assert lib.pg_bench_fused_norm(M, N, K, S, 20, C.byref(a), C.byref(b), C.byref(c), bad) == 0
+    assert (bad[0], bad[1], bad[2]) == (0, 0, 0), list(bad)

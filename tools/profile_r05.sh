@@ -1,9 +1,10 @@
 #!/bin/bash
-# Round-4 evidence pass on the GPU box (summaries only come back):
+# Round-5 evidence pass on the GPU box (summaries only come back):
 #   kernel traces of one bench step at bs = 64 / 32 / 8, MFMA-utilisation counters of the MFMA kernels (prefill, VQ, SigLIP),
 #   the HBM-traffic passes of the dominant kernel (pmc_attn.json), secondary-workload lines.
-# usage: gpurun --timeout 2400 -- 'bash tools/profile_r04.sh r04'
-tag=${1:-r04}
+#   + SQ wave-state / LDS counters of the MFMA kernels the verdict names (where do their wave cycles go).
+# usage: gpurun --timeout 2400 -- 'bash tools/profile_r05.sh r05'
+tag=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -28,6 +29,16 @@ pmc() {   # name, program args...
 } > $OUT/${tag}_mfma_counters.md 2>&1
 rm -rf $OUT/pmc_${tag}_prefill $OUT/pmc_${tag}_vq $OUT/pmc_${tag}_vit
 cat $OUT/${tag}_mfma_counters.md
+{
+  echo "## SQ wave-state / LDS counters (tools/pmc_sq.sh; share of SQ_WAVE_CYCLES)"
+  echo "### conv3x3_halo_kernel (VQ decode, tools/vq_only.py 64 1)"; bash $ROOT/tools/pmc_sq.sh ${tag}_halo conv3x3_halo_kernel tools/vq_only.py 64 1
+  echo "### gemm256_kernel<ConvLoader> (VQ decode)"; bash $ROOT/tools/pmc_sq.sh ${tag}_g256c gemm256_kernelI11ConvLoader tools/vq_only.py 64 1
+  echo "### gn_apply_kernel (VQ decode)"; bash $ROOT/tools/pmc_sq.sh ${tag}_gn gn_apply_kernel tools/vq_only.py 64 1
+  echo "### gemm256_kernel<PlainLoader> (prefill of the bench batch)"; bash $ROOT/tools/pmc_sq.sh ${tag}_g256p gemm256_kernelI12PlainLoader bench.py --no-cpu-baseline --no-roofline --no-shard-check --no-rccl-selftest --batch 64 --steps 1 --warmup 0 --tokens 1
+  echo "### attn_prefill_flash2_kernel (prefill)"; bash $ROOT/tools/pmc_sq.sh ${tag}_fl2 attn_prefill_flash2_kernel bench.py --no-cpu-baseline --no-roofline --no-shard-check --no-rccl-selftest --batch 64 --steps 1 --warmup 0 --tokens 1
+} > $OUT/${tag}_sq_counters.md 2>&1
+cat $OUT/${tag}_sq_counters.md
+cd /tmp
 BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-roofline --no-shard-check --no-rccl-selftest --batch 64 --steps 1 --warmup 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_${tag}_$c
