@@ -267,3 +267,21 @@ def test_fullconfig_fixture_is_consistent():
                 assert abs(float(g["sel_logits"][si, b, hit[0]]) - float(g["top_v"][st, b, 0])) < 1e-6
     assert g["pooled"].shape == (2, 3, 48, 48) and g["crop0"].shape == (3, 32, 32) and np.isfinite(g["pooled"]).all()
     assert 0.05 < float(g["img_std"].min()) and float(np.abs(g["pooled"]).max()) < 4.0
+
+
+def test_fullconfig_text_fixture_is_consistent():
+    """tests/golden/generate_fullconfig.npz (oracle/make_golden.py::golden_text_full_config): greedy text decode at 24 layers x vocab 102 400."""
+    g = load_golden("generate_fullconfig.npz")
+    ids, mask, out, probe = g["ids"], g["mask"], g["out"], g["probe"]
+    assert ids.shape == mask.shape == (6, 96) and out.shape == probe.shape == (6, 24)
+    for r in range(6):
+        n = int(mask[r].sum())
+        assert (mask[r, 96 - n:] == 1).all() and ids[r, 96 - n] == 1                      # left-padded, BOS first
+    eos = int(g["eos"])
+    stopped = (out == eos).any(1)
+    assert 1 <= int(stopped.sum()) < 6
+    for r in range(6):                                                                    # out == probe up to and including the first EOS, EOS-padded behind it
+        hit = np.nonzero(probe[r] == eos)[0]
+        n = int(hit[0]) + 1 if hit.size else 24
+        assert (out[r, :n] == probe[r, :n]).all() and (out[r, n:] == eos).all()
+    assert np.array_equal(g["top_i"][..., 0].T, probe) and float(g["min_margin"]) > 1e-3
