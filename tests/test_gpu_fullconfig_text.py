@@ -63,7 +63,7 @@ def test_fullconfig_text_greedy_f32_matches_hf_generate():
 
 
 def test_fullconfig_text_greedy_bf16_vs_oracle_logits():
-    TEXT_TOL = 0.12                      # 1.5x+ the worst gap measured on MI355X (printed); the 2-layer fixtures measure 0.025-0.046
+    TEXT_TOL = 0.09                      # 1.5x the worst gap measured on MI355X in round 5: 0.060 (argmax agreement 92.4 %; the 2-layer fixtures measure 0.025-0.046)
     s = _setup()
     g = s["g"]
     unused = int(g["unused_eos"])
