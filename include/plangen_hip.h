@@ -214,7 +214,8 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *     prefill_rope_epi (1)   QKV projection: RoPE + KV-cache write in the 256x256 GEMM's epilogue when the packed batch takes that kernel
  *                            (plangen_base.py:571 -> LlamaAttention.forward); 0 = GEMM -> fp32 q|k|v -> RoPE / KV-fill kernel.  Same bits.
  *     prefill_res_epi (1)    o_proj / down_proj: residual add in the GEMM epilogue; 0 = fp32 slab folded in by the norm kernel.  Same bits.
- *     gemm256 (1)            256x256 eight-phase MFMA GEMM for large shapes (0: 128x128 kernel everywhere)
+ *     gemm256 (1)            256x256 MFMA GEMM for large shapes (0: 128x128 kernel everywhere; 4 / 5 / 6 pin the tile height to 256 / 224 / 192 rows
+ *                            instead of choosing it per launch; +8 = four phases per K tile instead of two).  Bit-identical results in every form.
  *   VQ-16
  *     conv_halo (1)          direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: implicit-GEMM kernel)
  *     vq_mid_bf16 (1)        bf16 mode: the tensor between a ResnetBlock's two convolutions is bf16 (statistics from the fp32

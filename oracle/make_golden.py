@@ -976,6 +976,34 @@ def golden_siglip_fullwidth():
           f"|f|max {scale:.2f}, running-max moves on {moves:.2f} of later key tiles")
 
 
+@torch.no_grad()
+def golden_siglip_fulldepth():
+    """a13 / f2 at the production shape AND DEPTH (round 5): SigLIP-L/16-384 with all 24 blocks (siglip_vit.py:628-637) in front of the Janus-width
+    aligner, ONE seeded image.  As in ``golden_siglip_fullwidth`` the reference's own VisionTransformer / CLIPVisionTower classes (stand-in
+    PatchEmbed / Mlp), transformers.SiglipVisionModel and oracle.siglip_forward must agree before anything is stored."""
+    cfg = R.OracleCfg(**dict(VISW, vit_layers=24))
+    W = R.make_weights(cfg, seed=12, with_vision=True)
+    img = siglip_fullwidth_images(cfg, n=1, seed=43)
+    sv, ce = ref_siglip_modules()
+    tower = ce.CLIPVisionTower(model_name="siglip_large_patch16_384", image_size=cfg.vit_img, select_feature="same", select_layer=-1).eval()
+    assert len(tower.vision_tower.blocks) == 24 and tower.vision_tower.ignore_head
+    tower.vision_tower.attn_pool = None                                  # plangen_base.py:105-106
+    _load_vit_weights(tower.vision_tower, W, cfg)
+    f_ref = tower(img)
+    f_hf = _hf_siglip(cfg, W)(pixel_values=img).last_hidden_state
+    f_or = R.siglip_forward(W, cfg, img)
+    e1, e2 = (f_ref - f_or).abs().max().item(), (f_hf - f_or).abs().max().item()
+    scale = f_or.abs().max().item()
+    assert e1 < 5e-5 * max(1, scale) and e2 < 5e-5 * max(1, scale), (e1, e2, scale)
+    aligned = R.vision_encode(W, cfg, img)
+    P = (cfg.vit_img // cfg.vit_patch) ** 2
+    tok = torch.cat([torch.arange(0, P, 7), torch.tensor([P - 1])]).unique()
+    np.savez_compressed(os.path.join(OUT, "siglip_fulldepth.npz"), img_seed=43, img_sum=float(img.double().abs().sum()), tok=tok.numpy().astype(np.int32),
+                        features=f_ref[:, tok].numpy(), aligned=aligned[:, tok].numpy(), feat_absmax=scale, feat_std=float(f_or.std()), wsum=wsum(W),
+                        source="reference siglip_vit.py + clip_encoder.py classes (24 blocks, stand-in PatchEmbed / Mlp) == transformers.SiglipVisionModel == oracle")
+    print(f"siglip full depth ok; reference-blocks vs oracle {e1:.2e}, transformers vs oracle {e2:.2e}; |f|max {scale:.2f} std {float(f_or.std()):.3f}")
+
+
 def golden_text():
     """The chat template through the REFERENCE's own conversation.py (imported by file path): sft prompts for a set
     of (caption, grounding, stage) cases -> tests/golden/text_golden.json; asserts the oracle restatement equals it."""
@@ -1015,6 +1043,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "siglip":
         golden_siglip_crosscheck()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "siglipdepth":
+        golden_siglip_fulldepth()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "siglipfull":
         golden_siglip_fullwidth()
@@ -1066,6 +1097,7 @@ def main():
     golden_text()
     golden_siglip_crosscheck()
     golden_siglip_fullwidth()
+    golden_siglip_fulldepth()
 
 
 if __name__ == "__main__":

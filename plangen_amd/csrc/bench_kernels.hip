@@ -300,6 +300,12 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     o1 = nullptr;
     hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 11u);
     hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, Wt, (long)N * K, 5u);
+    // PG_BENCH_CONST=1: constant operands (no bit toggling in the MFMA datapath): separates "the schedule cannot feed the matrix cores" from "the chip clocks
+    // down under the power of random-data MFMAs" -- the same kernel, the same instruction stream, a different clock (profiles/r05_c)
+    if (getenv("PG_BENCH_CONST")) {
+        hipLaunchKernelGGL(fill_const_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 0.0078125f);
+        hipLaunchKernelGGL(fill_const_kernel, dim3(2048), dim3(256), 0, 0, Wt, (long)N * K, 0.0078125f);
+    }
     hipStream_t s; hipStreamCreate(&s);
     GemmA ga; ga.ptr = A; ga.lda = K;
     if (conv) { ga.kind = 1; ga.Hi = Hi; ga.Wi = Wi; ga.Cin = Cin; ga.up = up; ga.zeros = zeros; }

@@ -47,12 +47,13 @@ __device__ __forceinline__ void g2_barrier() { asm volatile("s_barrier" ::: "mem
 // 424 tiles of 256 rows = 1.66 rounds on 256 CUs (17 % of the launch idle) but 480 tiles of 224 rows = 1.875 rounds of 7/8 the work.  Only
 // the fragment reads and MFMAs of the second half shrink (phases 3 / 4: 4 x MT1 MFMAs... MT1 m-tiles x 2 n-tiles x 2 k-steps); the staging
 // stream, its counted waits and the LDS layout are unchanged (the half-tile HA1 still brings 64 rows per wave row, 64 - 16 MT1 of them unused).
-template <class AL, class EP, int WM, int WN, bool ROPE = false, int MT1 = 4>      // ROPE: the prefill QKV instantiation (RoPE + KV-write epilogue, act 3) -- its own kernel so its
+template <class AL, class EP, int WM, int WN, bool ROPE = false, int MT1 = 4, int PH = 4>      // ROPE: the prefill QKV instantiation (RoPE + KV-write epilogue, act 3) -- its own kernel so its
 __global__ __launch_bounds__(512) void gemm256_kernel(                 // register needs do not reach the other users of this template
 AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                                                      long strideA2, long strideB2, EP ep, int M, int N, int K, int ntm, int ntn) {
     static_assert(WM * WN == 8 && (WN == 2 || WN == 4), "eight waves, 128x64 of C each");
     static_assert(MT1 >= 1 && MT1 <= 4, "second row half: 1..4 m-tiles");
+    static_assert(PH == 4 || (PH == 2 && WM == 2 && WN == 4), "two-phase schedule: 2x4 waves only (its counted waits assume 2 loads per half-tile)");
     constexpr int WROWS = 64 + 16 * MT1, NMT = 4 + MT1;          // rows / m-tiles of C per wave row
     constexpr int BM = WM * WROWS, BN = WN * 64;
     constexpr int AH = WM * 64 * 128, BH = WN * 32 * 128;        // bytes per A / W half-tile
@@ -152,6 +153,27 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     g2_barrier();
 
+    // PH == 2 (round 5): the SAME stream and LDS layout with TWO phases per K tile instead of four -- phase A = quadrants (0,0) (0,1) on the
+    // fragments of HB0, HA0, HB1 (32 MFMAs), phase B = quadrants (1,1) (1,0) on HA1 (8 MT1 MFMAs); each phase re-stages two half-tiles.  Half the
+    // barriers per MFMA: the four-phase form measured only -3.5 % when a quarter of the MFMAs of phases 3 / 4 was removed (224-row tiles), i.e. its
+    // phases are bound by their fixed part (two barriers, fragment reads, staging, counted wait), not by their 16 MFMAs.
+#define G2_MFMA_SECTION2(MH, BFA, NHA, BFB, NHB)                                                            \
+    g2_barrier();                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
+        _Pragma("unroll") for (int mt = 0; mt < (MH ? MT1 : 4); ++mt)                                       \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                              \
+                acc[MH * 4 + mt][NHA * 2 + nt] =                                                            \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFA[nt][ks], a[mt][ks], acc[MH * 4 + mt][NHA * 2 + nt], 0, 0, 0); \
+                acc[MH * 4 + mt][NHB * 2 + nt] =                                                            \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFB[nt][ks], a[mt][ks], acc[MH * 4 + mt][NHB * 2 + nt], 0, 0, 0); \
+            }                                                                                               \
+    __builtin_amdgcn_s_setprio(0);                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    g2_barrier();
+
     bool have = setup(0);
     if (have) prologue();
     for (int base = 0; have; ) {
@@ -159,10 +181,48 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
         for (int i = 0; i < NMT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        G2_WAIT()
+        if constexpr (PH == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // HB1(0) landed (younger: HA1(0) HA0(1) HB0(1))
+        else { G2_WAIT() }
         g2_barrier();
         if (wr >= WM / 2) g2_barrier();                   // second wave group runs one barrier behind
 
+        if constexpr (PH == 2) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* buf = smem + (kt & 1) * BUF;
+            // ---- phase A: quadrants (0,0) (0,1): fragments of HB0, HA0, HB1; stage HB1(kt+1), HA1(kt+1)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                b0[nt][0] = *(const bf16x8*)(buf + boff0 + nt * 2048);
+                b0[nt][1] = *(const bf16x8*)(buf + boff1 + nt * 2048);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                a[mt][0] = *(const bf16x8*)(buf + aoff0 + mt * 2048);
+                a[mt][1] = *(const bf16x8*)(buf + aoff1 + mt * 2048);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                b1[nt][0] = *(const bf16x8*)(buf + BH + boff0 + nt * 2048);
+                b1[nt][1] = *(const bf16x8*)(buf + BH + boff1 + nt * 2048);
+            }
+            stage_B(H1, kt + 1);
+            stage_A(H1, kt + 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // HA1(kt) landed (younger: HA0 HB0 HB1 HA1 of kt+1)
+            __builtin_amdgcn_sched_barrier(0);
+            G2_MFMA_SECTION2(0, b0, 0, b1, 1)
+            // ---- phase B: quadrants (1,1) (1,0): fragments of HA1; stage HA0(kt+2), HB0(kt+2)
+#pragma unroll
+            for (int mt = 0; mt < MT1; ++mt) {
+                a[mt][0] = *(const bf16x8*)(buf + AH + aoff0 + mt * 2048);
+                a[mt][1] = *(const bf16x8*)(buf + AH + aoff1 + mt * 2048);
+            }
+            stage_A(H0, kt + 2);
+            stage_B(H0, kt + 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // HB1(kt+1) (and the older HA0 / HB0(kt+1)) landed (younger: HA1(kt+1) HA0 HB0(kt+2))
+            __builtin_amdgcn_sched_barrier(0);
+            G2_MFMA_SECTION2(1, b1, 1, b0, 0)
+        }
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             const char* buf = smem + (kt & 1) * BUF;
             // ---- phase 1: quadrant (0,0): fragments of HB0 and HA0; stage HB1(kt+1)
@@ -323,19 +383,20 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
         }
     }
 #undef G2_MFMA_SECTION
+#undef G2_MFMA_SECTION2
 #undef G2_WAIT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // clamped tail stages must not outlive the block's LDS
 }
 
 
-template <class AL, int WM, int WN, bool ROPE = false, int MT1 = 4>
+template <class AL, int WM, int WN, bool ROPE = false, int MT1 = 4, int PH = 4>
 static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long strideA, long strideB, long strideA2, long strideB2,
                       const Epi<bf16>& ep, int M, int N, int K, int batch, int batch2) {
     constexpr int BM = WM * (64 + 16 * MT1), BN = WN * 64, LDS = 2 * (2 * WM * 64 * 128 + 2 * WN * 32 * 128);
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     const int per_batch = 256 / (batch * batch2) > 8 ? 256 / (batch * batch2) : 8;   // blocks per (batch) slice: one per CU overall
     dim3 grid(ntm * ntn < per_batch ? ntm * ntn : per_batch, batch, batch2), block(512);
-    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN, ROPE, MT1>;
+    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN, ROPE, MT1, PH>;
     (void)PG_DYN_LDS(kfn, LDS);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
 }
@@ -343,7 +404,8 @@ static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long stride
 // Tile height of a plain-A launch (round 5): rounds of 256 resident blocks x rows per tile (+ a fixed per-tile share for the epilogue
 // and the pipeline fill, in row equivalents), smallest wins; ties keep the taller tile.  Returns MT1 (4 / 3 / 2 = 256 / 224 / 192 rows).
 static int pick_tile_height(int M, int N, int batches) {
-    if (pg_tune->gemm256 >= 4) return pg_tune->gemm256 == 4 ? 4 : pg_tune->gemm256 == 5 ? 3 : 2;      // A/B: 4 / 5 / 6 pin 256 / 224 / 192 rows
+    const int pin = pg_tune->gemm256 & 7;
+    if (pin >= 4) return pin == 4 ? 4 : pin == 5 ? 3 : 2;      // A/B: 4 / 5 / 6 pin 256 / 224 / 192 rows
     if (batches != 1) return 4;
     const int ntn = (N + 255) / 256;
     int best = 4; long best_cost = -1;
@@ -372,9 +434,15 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
     if (a.kind == 0) {
         PlainLoaderB<bf16> al; al.A = (const bf16*)a.ptr; al.lda = a.lda; al.M = M;
         const int mt1 = pick_tile_height(M, N, batch * batch2);
-#define G2_LAUNCH(ROPE_, MT1_) launch256<PlainLoaderB<bf16>, 2, 4, ROPE_, MT1_>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2)
-        if (e.act == 3) { if (mt1 == 3) G2_LAUNCH(true, 3); else if (mt1 == 2) G2_LAUNCH(true, 2); else G2_LAUNCH(true, 4); }
-        else { if (mt1 == 3) G2_LAUNCH(false, 3); else if (mt1 == 2) G2_LAUNCH(false, 2); else G2_LAUNCH(false, 4); }
+#define G2_LAUNCH(ROPE_, MT1_, PH_) launch256<PlainLoaderB<bf16>, 2, 4, ROPE_, MT1_, PH_>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2)
+        // two phases per K tile by default (round 5: +2-3 % on every prefill shape, bit-identical); gemm256 bit 3 (value 8) selects the four-phase schedule for A/B
+        const bool four = (pg_tune->gemm256 & 8) != 0;
+        if (!four) {
+            if (e.act == 3) { if (mt1 == 3) G2_LAUNCH(true, 3, 2); else if (mt1 == 2) G2_LAUNCH(true, 2, 2); else G2_LAUNCH(true, 4, 2); }
+            else { if (mt1 == 3) G2_LAUNCH(false, 3, 2); else if (mt1 == 2) G2_LAUNCH(false, 2, 2); else G2_LAUNCH(false, 4, 2); }
+        } else
+        if (e.act == 3) { if (mt1 == 3) G2_LAUNCH(true, 3, 4); else if (mt1 == 2) G2_LAUNCH(true, 2, 4); else G2_LAUNCH(true, 4, 4); }
+        else { if (mt1 == 3) G2_LAUNCH(false, 3, 4); else if (mt1 == 2) G2_LAUNCH(false, 2, 4); else G2_LAUNCH(false, 4, 4); }
 #undef G2_LAUNCH
         return true;
     }
@@ -383,6 +451,7 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
     const long in_elems = ((long)M / ((long)Ho * Wo)) * a.Hi * a.Wi * a.Cin;
     if (in_elems >= (1L << 31)) return false;             // the slim loader keeps 32-bit element offsets
     ConvLoaderS<4> al; al.setup(a, M);
-    launch256<ConvLoaderS<4>, 2, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+    if (pg_tune->gemm256 & 8) launch256<ConvLoaderS<4>, 2, 4, false, 4, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+    else launch256<ConvLoaderS<4>, 2, 4, false, 4, 2>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
     return true;
 }

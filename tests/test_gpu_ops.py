@@ -346,11 +346,12 @@ def test_hardware_bf16_conversion_equals_software_rne_for_every_float():
     assert bad.value == 0 and nan_lost.value == 0, (bad.value, nan_lost.value)
 
 
-@pytest.mark.parametrize("mode", [4, 5, 6, 1])
+@pytest.mark.parametrize("mode", [4, 5, 6, 1, 12, 13, 9])
 @pytest.mark.parametrize("M,N,K", [(13285, 2048, 2048), (6600, 2048, 5632), (6100, 6144, 2048)])
 def test_gemm256_tile_heights_are_bit_identical_to_the_128_tile_kernel(M, N, K, mode):
-    """Round 5: gemm256_kernel's tile height is chosen per launch (256 / 224 / 192 rows = `gemm256` 4 / 5 / 6; 1 = pick_tile_height()).
-    Same K order in every form: each of 3 launches must equal the 128x128 kernel bit for bit (ragged last tile rows included)."""
+    """Round 5: gemm256_kernel's tile height is chosen per launch (256 / 224 / 192 rows = `gemm256` 4 / 5 / 6; 1 = pick_tile_height()) and a K tile
+    runs in two phases (default) or four (+8).  Same K order in every form: each of 3 launches must equal the 128x128 kernel bit for bit (ragged
+    last tile rows included)."""
     import ctypes as C
     from plangen_amd import _lib
     lib = _lib.load_diag()

@@ -1,0 +1,76 @@
+"""GPU: the SigLIP-L/16-384 tower at its production shape AND DEPTH (24 blocks, width 1024, 16 heads x 64, MLP 4096, 576 tokens) + the
+Janus-width aligner against tests/golden/siglip_fulldepth.npz (oracle/make_golden.py::golden_siglip_fulldepth: the reference's own
+siglip_vit.py / clip_encoder.py classes with labelled stand-ins for timm's PatchEmbed / Mlp == transformers.SiglipVisionModel == oracle,
+all three agreeing exactly).  What the 2-block fixture (tests/test_gpu_vision_full.py) cannot show: rounding accumulated over 24 blocks and
+the per-block weight strides at the real depth (BASELINE configs[4], rows a13 / f2; parity still "unpinned" in the strict sense: timm is absent).
+PG_F32: features / aligned within F32_TOL.  PG_BF16: error statistics printed, bounds 1.5x the measured values."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from fullwidth_cfg import VISW, siglip_fullwidth_images
+from oracle import ref_cpu as R
+
+pytestmark = pytest.mark.gpu
+
+_S = {}
+F32_TOL = 2e-3
+FEAT_TOL_BF16, ALIGNED_TOL_BF16 = 0.065, 0.07       # 1.5x the values measured on MI355X in round 5: features max 0.041 (p99 0.023, p50 0.006; feature std 1.0), aligned max 0.044
+
+
+def _setup():
+    if not _S:
+        from plangen_amd.config import PlanGenConfig
+        g = load_golden("siglip_fulldepth.npz")
+        kw = dict(VISW, vit_layers=24)
+        ocfg = R.OracleCfg(**kw)
+        W = R.make_weights(ocfg, seed=12, with_vision=True)
+        ws = float(sum(v.double().abs().sum() for v in W.values()))
+        assert abs(ws - float(g["wsum"])) < 1e-6 * ws
+        img = siglip_fullwidth_images(n=1, seed=int(g["img_seed"]))
+        assert abs(float(img.double().abs().sum()) - float(g["img_sum"])) < 1e-6 * float(g["img_sum"])
+        _S.update(W=W, g=g, cfg=PlanGenConfig(**kw), img=img)
+    return _S
+
+
+def _run(dtype):
+    from plangen_amd.engine import Engine
+    s = _setup()
+    cfg = s["cfg"]
+    e = Engine(cfg, dtype=dtype, max_rows=4, max_prompt=32, max_new=8, max_images=1, with_vision=True, max_vision_images=1)
+    e.load_state_dict(s["W"])
+    try:
+        out = e.vision_encode(s["img"]).float().cpu()
+        P, C = cfg.vit_tokens, cfg.vit_width
+        feat = e.debug_read("vit_feat", 0, P * C, torch.float32 if dtype == "f32" else torch.bfloat16).float().cpu().reshape(1, P, C)
+        tok = torch.from_numpy(s["g"]["tok"]).long()
+        return out[:, tok], feat[:, tok]
+    finally:
+        e.close()
+
+
+def test_siglip_fulldepth_f32_matches_reference_blocks():
+    g = _setup()["g"]
+    al, ft = _run("f32")
+    ref_f, ref_a = torch.from_numpy(g["features"]), torch.from_numpy(g["aligned"])
+    ef, ea = (ft - ref_f).abs().max().item(), (al - ref_a).abs().max().item()
+    print(f"siglip 24 blocks f32: features err {ef:.2e} (|f| max {float(g['feat_absmax']):.2f}), aligned err {ea:.2e} (|a| max {ref_a.abs().max():.2f})")
+    assert ef < F32_TOL * max(1.0, ref_f.abs().max().item()) and ea < F32_TOL * max(1.0, ref_a.abs().max().item())
+
+
+def test_siglip_fulldepth_bf16_error_statistics():
+    g = _setup()["g"]
+    al, ft = _run("bf16")
+    ref_f, ref_a = torch.from_numpy(g["features"]), torch.from_numpy(g["aligned"])
+    df, da = (ft - ref_f).abs(), (al - ref_a).abs()
+    stats = dict(feat_max=df.max().item(), feat_p99=df.flatten().quantile(0.99).item(), feat_p50=df.flatten().quantile(0.5).item(), feat_std=float(g["feat_std"]),
+                 aligned_max=da.max().item(), aligned_p99=da.flatten().quantile(0.99).item(), aligned_scale=ref_a.abs().max().item())
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(stats, open(os.path.join(ROOT, "gpurun_out", "siglip_fulldepth_bf16_stats.json"), "w"), indent=1)
+    print("siglip 24 blocks bf16:", stats)
+    assert stats["feat_max"] < FEAT_TOL_BF16 and stats["aligned_max"] < ALIGNED_TOL_BF16, stats
+    assert stats["feat_p99"] < 0.5 * FEAT_TOL_BF16, stats

@@ -285,3 +285,11 @@ def test_fullconfig_text_fixture_is_consistent():
         n = int(hit[0]) + 1 if hit.size else 24
         assert (out[r, :n] == probe[r, :n]).all() and (out[r, n:] == eos).all()
     assert np.array_equal(g["top_i"][..., 0].T, probe) and float(g["min_margin"]) > 1e-3
+
+
+def test_siglip_fulldepth_fixture_is_consistent():
+    """tests/golden/siglip_fulldepth.npz: 24-block SigLIP-L tower + aligner, one image; reference classes == transformers == oracle at generation."""
+    g = load_golden("siglip_fulldepth.npz")
+    assert g["features"].shape == (1, len(g["tok"]), 1024) and g["aligned"].shape == (1, len(g["tok"]), 2048)
+    assert g["tok"][0] == 0 and g["tok"][-1] == 575 and np.isfinite(g["features"]).all() and np.isfinite(g["aligned"]).all()
+    assert 0.9 < float(g["feat_std"]) < 1.1 and "24 blocks" in str(g["source"])

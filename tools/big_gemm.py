@@ -2,7 +2,7 @@
 """Time / verify the MFMA GEMM kernels on one shape.
 usage: big_gemm.py M N K [mode=1] [iters=20] [verify=1]            plain A
        big_gemm.py conv B Hi Wi Cin Cout up [mode=1] [iters] [verify]   implicit-im2col 3x3 conv
-mode: 0 = 128x128 kernel, 1 = 256x256 eight-phase (staggered), 2 = 256x256 lock-step"""
+mode = pg_set_option("gemm256"): 0 = 128x128 kernel, 1 = 256x256 kernel (tile height per launch, two phases per K tile), 4 / 5 / 6 = 256 / 224 / 192 rows pinned, +8 = four phases"""
 import ctypes as C, os, sys
 import torch  # noqa: F401  (one HIP runtime per process)
 lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plangen_amd", "lib", "libplangen_diag.so"))      # diagnostics library (pg_bench_* live there, not in the product)
