@@ -310,6 +310,11 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     GemmA ga; ga.ptr = A; ga.lda = K;
     if (conv) { ga.kind = 1; ga.Hi = Hi; ga.Wi = Wi; ga.Cin = Cin; ga.up = up; ga.zeros = zeros; }
     GemmEpi e; e.out = o0; e.out_f32 = getenv("PG_BENCH_OUT_BF16") ? 0 : 1; e.ldc = N;      // bf16 output: timing only (verify = 0)
+    float* gnp = nullptr; int gn_ns = 0;
+    if (conv && getenv("PG_BENCH_GN")) {          // GroupNorm partial sums from the halo convolution's epilogue (what the VQ pipeline runs), timing only
+        hipMalloc((void**)&gnp, (size_t)B * 8192 * 64 * 4);
+        ga.gn_part = gnp; ga.gn_nsplit = &gn_ns;
+    }
     PgTune tune; const PgTune* const saved = pg_tune; pg_tune = &tune;
     if (getenv("PG_CONV_HALO")) tune.conv_halo = atoi(getenv("PG_CONV_HALO"));
     hipDeviceSynchronize();
@@ -334,7 +339,7 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     *us_out = ms * 1000.f / iters;
     pg_tune = saved;
     const int rc = hipGetLastError() == hipSuccess ? 0 : -1;
-    hipFree(A); hipFree(Wt); hipFree(zeros); hipFree(o0); if (o1) hipFree(o1); hipFree(md);
+    hipFree(A); hipFree(Wt); hipFree(zeros); hipFree(o0); if (o1) hipFree(o1); hipFree(md); if (gnp) hipFree(gnp);
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
     return rc;
 }
