@@ -326,7 +326,7 @@ def loop_roofline(cfg, dtype, B, L, T, pad, decode_ms, uncond_shared):
                     "measured loop of the last timed step; moved_* = the bytes the kernels actually stream (pads skipped, shared negative prompt read once)"}
 
 
-def instrumented_pass(eng, args, cfg, B, L, T, ids, pad, tm):
+def instrumented_pass(eng, args, cfg, B, L, T, ids, pad, tm, phase_ms=None):
     """Right after the timed region, same batch, eager launches: HIP events ON THE LAUNCH STREAM around every decode kernel class on every
     --time-stride-th step.  Dominant kernel = decode attention (HBM-bound K/V streaming).  Returns the ``roofline`` object (or None)."""
     import torch
@@ -375,12 +375,15 @@ def instrumented_pass(eng, args, cfg, B, L, T, ids, pad, tm):
         ntok = sum(L - p for i, p in enumerate(pad) if i % 2 == 0) + (L - pad[1])        # shared uncond prompt prefilled once
         lens = [L - p for i, p in enumerate(pad) if i % 2 == 0] + [L - pad[1]]
         fl = 2.0 * ntok * cfg.n_layers * WEIGHT_PARAMS_LAYER + sum(4.0 * cfg.n_layers * cfg.hidden * n * (n + 1) / 2 for n in lens)
-        tf = fl / (tm["prefill_ms"] * 1e-3) / 1e12
-        classes["prefill (packed GEMMs + flash attention)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["prefill_ms"],
-                                                               "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
+        p_ms = phase_ms["prefill"]["mean"] if phase_ms and "prefill" in phase_ms else tm["prefill_ms"]
+        tf = fl / (p_ms * 1e-3) / 1e12
+        classes["prefill (packed GEMMs + flash attention)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": p_ms, "ms_last_step": tm["prefill_ms"],
+                                                               "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS,
+                                                               "timed": "mean over the timed steps (events around pg_prefill)" if phase_ms else "last timed step"}
         fl = VQ_DECODE_GFLOP_PER_IMAGE * 1e9 * B
-        tf = fl / (tm["vq_ms"] * 1e-3) / 1e12
-        classes["vq_decode (convs + GroupNorm + AttnBlock)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": tm["vq_ms"],
+        v_ms = phase_ms["vq_decode"]["mean"] if phase_ms and "vq_decode" in phase_ms else tm["vq_ms"]
+        tf = fl / (v_ms * 1e-3) / 1e12
+        classes["vq_decode (convs + GroupNorm + AttnBlock)"] = {"bound": "mfma", "gflop": fl / 1e9, "ms": v_ms, "ms_last_step": tm["vq_ms"],
                                                                 "achieved_tflops": tf, "frac": tf / MFMA_PEAK_TFLOPS}
     # rocprofv3 kernel durations of the same classes (the event-timed intervals above read ~2 us high on short kernels): attached only when
     # profiles/kernel_classes_b<B>.json was measured on exactly the kernel sources this process runs (tools/trace_classes.py)
@@ -559,10 +562,19 @@ def run_rank(args):
     # skips its device probe (a 4-byte read + stream sync per batch).
     uncond_shared = Engine.uncond_rows_shared(ids.cpu(), pad)
 
-    def step(seed, n_tok=T, decode_pixels=True):
+    phase_events = []            # per timed step: 4 events on the launch stream (recorded asynchronously, read after the final fence)
+
+    def step(seed, n_tok=T, decode_pixels=True, record=False):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
+        if ev: ev[0].record()
         eng.prefill(ids, pad, position_mode=0, uncond_shared=uncond_shared)
+        if ev: ev[1].record()
         toks = eng.decode_image_tokens(T=n_tok, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=seed)
+        if ev: ev[2].record()
         img = eng.vq_decode(toks) if (decode_pixels and n_tok == cfg.img_tokens) else None
+        if ev:
+            ev[3].record()
+            phase_events.append(ev)
         all_toks = gather_rows(toks, nB)          # rank 0: [G, T]; others: None
         return all_toks, img
 
@@ -577,7 +589,7 @@ def run_rank(args):
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
+        step(k, record=True)
     fence()
     dt_local = time.perf_counter() - t0
     dt = dt_local
@@ -602,6 +614,11 @@ def run_rank(args):
                    "parallelism": "prompt-sharded x%d" % world},
         "image_tokens_per_sec_per_gpu": B * T * args.steps / dt,
         "last_step_ms": {"prefill": tm["prefill_ms"], "decode_loop": tm["decode_ms"], "vq_decode": tm["vq_ms"]},
+        # every timed step's phases (events on the launch stream around the three calls of a step): mean and min over the K steps; the
+        # MFMA-bound class fractions below use the MEAN (the last step alone is one sample of a quantity that moves +-2 % with the chip's clock)
+        "phase_ms": {k: {"mean": sum(v) / len(v), "min": min(v), "max": max(v)} for k, v in (
+            ("prefill", [e[0].elapsed_time(e[1]) for e in phase_events]), ("decode_loop", [e[1].elapsed_time(e[2]) for e in phase_events]),
+            ("vq_decode", [e[2].elapsed_time(e[3]) for e in phase_events])) if v},
         "device_gb": eng.device_bytes() / 2 ** 30,
         "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": backend,
         "rank_ms_per_step": rank_ms,
@@ -637,7 +654,7 @@ def run_rank(args):
         out["pipelined"] = pipelined_pass(eng, args, cfg, B, T, ids, pad, uncond_shared, args.pipeline)
         out["pipelined_images_per_s"] = out["pipelined"]["pipelined_images_per_s"]
     if not args.no_roofline and rank == 0:
-        rf = instrumented_pass(eng, args, cfg, B, L, T, ids, pad, tm)
+        rf = instrumented_pass(eng, args, cfg, B, L, T, ids, pad, tm, out.get("phase_ms"))
         if rf:
             out["roofline"] = rf
             if not args.no_gemm_phase:

@@ -128,7 +128,7 @@ __device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t a, uint64_t
 
 // One row of (split-K reduce + residual add + RMSNorm) by a 256-thread block (rmsnorm_kernel and the
 // norm blocks of the fused norm+GEMM launch share it).  ``red``: >= 4 floats of LDS.
-template <typename T, int NV, bool SC1 = false, int SB = 4, int NT = 256>      // SB: slabs loaded in the up-front batch (4, or 8 for S > 4); NT: threads per row
+template <typename T, int NV, bool SC1 = false, int SB = 4, int NT = 256>      // SB: slabs loaded in the up-front batch (4, or 8 for S > 4; 0 = the caller guarantees S == 0: no slab loads at all -- prefill, round 5); NT: threads per row
 __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const float* __restrict__ partial,
                                             int S, long slab, const T* __restrict__ w,
                                             T* __restrict__ xn, int H, float eps, float* red) {
@@ -147,12 +147,13 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
     // straight-line batch (a plain ``for s`` loop is not unrolled by hipcc for runtime S and degenerates into S dependent round trips;
     // and with the batch inside the per-vector loop the second vector's loads waited for the first vector's adds: two round trips
     // per row at NV = 2, 5.2 us per launch)
-    f32x4 t[NV][SB];
+    f32x4 t[NV][SB > 0 ? SB : 1];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i = tid * 4 + j * (NT * 4);
         const int ic = i < H ? i : 0;                                  // clamped: loads unconditional, results discarded
         v[j] = *(const f32x4*)(xr + ic);
+        if constexpr (SB == 0) continue;                               // S == 0 by contract: the branch-free form below would re-read the row SB times for nothing
         // branch-free: S == 0 (no slabs, ``partial`` may be null) reads the residual row again and discards it; a conditional load
         // makes hipcc drain vmcnt at every join
         const float* pp = (S > 0 ? partial + (long)m * H : xr) + ic;
