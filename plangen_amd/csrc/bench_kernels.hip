@@ -315,7 +315,7 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
         hipMalloc((void**)&gnp, (size_t)B * 8192 * 64 * 4);
         ga.gn_part = gnp; ga.gn_nsplit = &gn_ns;
     }
-    PgTune tune; const PgTune* const saved = pg_tune; pg_tune = &tune;
+    PgTune tune; tune.diag = diag_hooks(); const PgTune* const saved = pg_tune; pg_tune = &tune;
     if (getenv("PG_CONV_HALO")) tune.conv_halo = atoi(getenv("PG_CONV_HALO"));
     hipDeviceSynchronize();
     if (verify) {
@@ -650,5 +650,136 @@ extern "C" int pg_bench_fused_norm(int M, int N, int K, int S, int iters, float*
     for (auto p : Ws) hipFree(p);
     hipFree(Wrow); hipFree(x); hipFree(wn); hipFree(xn); hipFree(xw); hipFree(slabs); hipFree(xa); hipFree(xb); hipFree(x0); hipFree(ssq); hipFree(ticket); hipFree(bad); hipFree(site);
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
+    return rc;
+}
+
+
+// ------------------------------------------------------------------------------- MFMA-only probe (round 5)
+// What dense bf16 rate do the matrix cores SUSTAIN on this chip with no memory traffic at all?  Every wave keeps NACC independent accumulators and
+// issues MFMAs back to back from registers; operands are random (bit toggling in the datapath) or constant.  mode 0: v_mfma_f32_16x16x32_bf16,
+// mode 1: v_mfma_f32_32x32x16_bf16.  The prefill GEMMs run at 1.0-1.09 PF on random data and 1.3 PF on constant data (profiles/r05_c): this
+// probe says how much of that gap is the chip's power / clock behaviour rather than the kernel's schedule.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* __restrict__ out, int iters, int constant) {
+    const int l = threadIdx.x & 63;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32x4 ua, ub;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t h = (uint32_t)(l * 131 + i * 17 + j * 7 + blockIdx.x * 977 + threadIdx.x) * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            uint32_t g = h * 2246822519u + 12345u; g ^= g >> 16;
+            // two bf16 per dword in [-1, 1): sign + exponent 0x3f00..0x3f7f + random mantissa
+            const uint32_t lo = constant ? 0x3c00u : ((h & 0x8000u) | 0x3f00u | (h & 0x7fu)), hi = constant ? 0x3c00u : ((g & 0x8000u) | 0x3f00u | (g & 0x7fu));
+            ua[j] = lo | (hi << 16);
+            const uint32_t lo2 = constant ? 0x3c00u : (((h >> 16) & 0x8000u) | 0x3f00u | ((h >> 8) & 0x7fu)), hi2 = constant ? 0x3c00u : (((g >> 16) & 0x8000u) | 0x3f00u | ((g >> 8) & 0x7fu));
+            ub[j] = lo2 | (hi2 << 16);
+        }
+        a[i] = *(const bf16x8*)&ua; b[i] = *(const bf16x8*)&ub;
+    }
+    if constexpr (MODE == 0) {
+        f32x4 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3];
+        if (s == 123.456f) out[threadIdx.x] = s;
+    } else {
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + r) & 3], b[i & 3], acc[i], 0, 0, 0);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][15];
+        if (s == 123.456f) out[threadIdx.x] = s;
+    }
+}
+
+// LDS-fed variant of the probe (mode 2): ONE wave per SIMD, per-wave tile 128 x 128 = 4 x 4 MFMA tiles of 32x32 (256 accumulator registers -> AGPRs),
+// per k-step (16) 4 A + 4 B fragments read from LDS with ds_read_b128 (double-buffered in registers: the reads of step s+1 are issued before the
+// 16 MFMAs of step s), LDS filled once with random bf16.  No global traffic, no barriers in the loop: the ceiling of a "big per-wave tile" GEMM main loop.
+__global__ __launch_bounds__(256) void mfma_lds_fed_kernel(float* __restrict__ out, int iters, int constant) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // 64 KiB: A [256 rows][128 B] | B [256 rows][128 B]
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    for (int i = tid; i < 65536 / 4; i += 256) {
+        uint32_t h = (uint32_t)(i * 2654435761u + blockIdx.x * 977u); h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        ((uint32_t*)smem)[i] = constant ? 0x3c003c00u : (((h & 0x8000u) | 0x3f00u | (h & 0x7fu)) | ((((h >> 16) & 0x8000u) | 0x3f00u | ((h >> 8) & 0x7fu)) << 16));
+    }
+    __syncthreads();
+    const int wr = w >> 1, wc = w & 1, lr = l & 31, kg = l >> 5;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 af[2][4], bfr[2][4];
+    auto rd = [&](int buf, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ra = wr * 128 + t * 32 + lr, rb = wc * 128 + t * 32 + lr;
+            const int c = ks * 2 + kg;
+            af[buf][t] = *(const bf16x8*)(smem + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
+            bfr[buf][t] = *(const bf16x8*)(smem + 32768 + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
+        }
+    };
+    rd(0, 0);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            rd((ks + 1) & 1, (ks + 1) & 3);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][15];
+    if (s == 123.456f) out[tid] = s;
+}
+// mode: 0 / 1 = MFMA shape; waves_per_simd 1..2 (block = 256 threads = 4 waves; grid = 256 CUs x waves_per_simd blocks); returns TFLOP/s over `ms_target` ms of work
+extern "C" int pg_bench_mfma_peak(int mode, int waves_per_simd, int constant, int iters, float* tflops_out, float* ms_out) {
+    float* out; if (hipMalloc((void**)&out, 4096) != hipSuccess) return -2;
+    hipStream_t s; hipStreamCreate(&s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const dim3 grid(256 * waves_per_simd), block(256);
+    if (mode == 2) (void)hipFuncSetAttribute((const void*)mfma_lds_fed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    auto launch = [&]() {
+        if (mode == 0) hipLaunchKernelGGL(mfma_peak_kernel<0>, grid, block, 0, s, out, iters, constant);
+        else if (mode == 1) hipLaunchKernelGGL(mfma_peak_kernel<1>, grid, block, 0, s, out, iters, constant);
+        else hipLaunchKernelGGL(mfma_lds_fed_kernel, dim3(256), block, 65536, s, out, iters, constant);
+    };
+    launch(); launch();
+    hipEventRecord(e0, s);
+    const int reps = 10;
+    for (int r = 0; r < reps; ++r) launch();
+    hipEventRecord(e1, s); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    // FLOPs per wave per iteration: mode 0: 16 MFMAs x 16*16*32*2; mode 1: 8 MFMAs x 32*32*16*2 -- both 262 144
+    // mode 2: 256 blocks x 4 waves x iters x 4 k-steps x 16 MFMAs x 32*32*16*2
+    const double fl = mode == 2 ? (double)reps * 256 * 4.0 * iters * 4 * 16 * 32768.0 : (double)reps * grid.x * 4.0 * iters * 262144.0;
+    *tflops_out = (float)(fl / (ms * 1e-3) / 1e12); *ms_out = ms / reps;
+    const int rc = hipGetLastError() == hipSuccess ? 0 : -2;
+    hipFree(out); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
     return rc;
 }

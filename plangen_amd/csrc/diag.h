@@ -16,6 +16,8 @@ bool launch_gemm_skinny_fused_norm(hipStream_t s, const bf16* x, const bf16* Wt,
 bool diag_attn_decode(hipStream_t s, bool is_bf16, const float* qkv, int S, long slab, void* obuf, void* kc, void* vc, const float* cos_t, const float* sin_t,
                       const SeqState& st, int M, int nh, int slots, int max_pos, float scale);
 const PgDiagHooks* diag_hooks();
+// diag_gemm_bw.hip: the "big-wave" 256x256 GEMM experiment (PgDiagHooks::gemm_big_wave; taken when pg_tune->gemm256 has bit 4 set)
+bool gemm_bw_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, const GemmEpi& e, int M, int N, int K, int batch, int batch2);
 
 // bench_kernels.hip: free-running weight-stream kernel (round 4's run-ahead prefetcher, measured 5-11 % SLOWER beside the decode loop,
 // profiles/r04_b; kept as the background memory-load stressor of the LDS-DMA hazard screens)

@@ -34,5 +34,6 @@ bool diag_attn_decode(hipStream_t s, bool is_bf16, const float* qkv, int S, long
 const PgDiagHooks* diag_hooks() {          // (a namespace-scope table would also be emitted for the device pass, which cannot see host functions)
     static PgDiagHooks h;
     h.attn_decode = diag_attn_decode;
+    h.gemm_big_wave = gemm_bw_try;
     return &h;
 }

@@ -173,6 +173,8 @@ template <> struct BigDispatch<bf16> {
     static void run(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long strideB, const GemmEpi& e,
                     int M, int N, int K, int batch, int batch2, long strideB2) {
         if (batch == 1 && batch2 == 1 && pg_tune->gemm256 && conv_halo_try(s, a, W, e, M, N, K, (float*)a.gn_part, a.gn_nsplit)) return;
+        // libplangen_diag.so only (round 5 experiment, profiles/r05_c): one wave per SIMD, 128 x 128 of C per wave, 32x32x16 MFMAs
+        if (pg_tune->diag && pg_tune->diag->gemm_big_wave && pg_tune->diag->gemm_big_wave(s, a, W, ldb, e, M, N, K, batch, batch2)) return;
         if (gemm256_try(s, a, W, ldb, strideB, e, M, N, K, batch, batch2, strideB2)) return;
         Epi<bf16> ep{e, M, N};
         const int ntm = (M + BIG_BM - 1) / BIG_BM, ntn = (N + BIG_BN - 1) / BIG_BN;

@@ -28,12 +28,13 @@ struct PgTune {
     int stream_gemm = -1;                                       // -1 auto, else bit mask: which decode GEMM classes run on the v4 LDS-DMA kernel (gemm.hip sk4_prod)
     const struct PgDiagHooks* diag = nullptr;                   // null in libplangen_hip.so; libplangen_diag.so (diag_api.hip) points it at its variant launchers
 };
-struct SeqState;
+struct SeqState; struct GemmA; struct GemmEpi;
 // Launch hooks only libplangen_diag.so fills in (measurement forms of production kernels; some produce WRONG results by construction).
 // A hook returns true when it launched something in place of the production kernel.
 struct PgDiagHooks {
     bool (*attn_decode)(hipStream_t s, bool is_bf16, const float* qkv, int S, long slab, void* obuf, void* kc, void* vc, const float* cos_t, const float* sin_t,
                         const SeqState& st, int M, int nh, int slots, int max_pos, float scale);
+    bool (*gemm_big_wave)(hipStream_t s, const GemmA& a, const bf16* W, long ldb, const GemmEpi& e, int M, int N, int K, int batch, int batch2);
 };
 extern thread_local const PgTune* pg_tune;
 struct GemmA {

@@ -30,7 +30,8 @@ def test_lds_dma_protocols_match_the_compiled_code():
     assert v.get("halo_lock", 0) == 2        # conv_halo=2 option kernels
     assert v.get("once", 0) == 1             # conv_out halo kernel
     assert v.get("sink", 0) >= 6             # run-ahead weight prefetcher instantiations: LDS-DMA into a sink that is never read
-    assert set(v) <= {"fifo", "halo_stag", "big", "halo_lock", "once", "sink"}  # every verified kernel is on a STRICT spec (no same-phase form left)
+    assert v.get("fifo_weak", 0) <= 1        # only the diagnostics library's big-wave GEMM experiment (diag_gemm_bw.hip) reads behind its retiring barrier
+    assert set(v) <= {"fifo", "fifo_weak", "halo_stag", "big", "halo_lock", "once", "sink"}  # every PRODUCT kernel is on a STRICT spec (no same-phase form left)
     assert r["sk4"]["rc"] == 0 and r["sk4"]["failed"] == 0 and r["sk4"]["checked"] >= 40   # production + bench instantiations of the decode GEMM
 
 
