@@ -157,6 +157,25 @@ def test_fullconfig_f32_through_t2i_tokens_bit_exact_pixels_within_1e4():
         e.close()
 
 
+@pytest.mark.parametrize("opt", ["use_graph", "lanes"])
+def test_fullconfig_f32_documented_fallbacks_produce_the_same_tokens(opt):
+    """The A/B fallbacks the header documents as result-neutral (hipGraph replay of the decode step, two row-range lanes) at the real
+    configuration: all 2 x 576 free-running fp32 tokens equal the fixture."""
+    from plangen_amd.engine import Engine
+    s = _setup()
+    g = s["g"]
+    ids, pad, _, _ = _prompts(g)
+    e = Engine(s["cfg"], dtype="f32", max_rows=4, max_prompt=256, max_new=576, max_images=2)
+    e.load_state_dict(s["W"])
+    try:
+        e.set_option(opt, 2 if opt == "lanes" else 1)
+        e.prefill(ids, pad, position_mode=0)
+        toks = e.decode_image_tokens(T=576, cfg_weight=5.0, temperature=0.0)
+        assert np.array_equal(toks.cpu().numpy(), g["tokens"])
+    finally:
+        e.close()
+
+
 def test_fullconfig_bf16_teacher_forced_and_pixels():
     from plangen_amd.engine import Engine
     s = _setup()
