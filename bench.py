@@ -153,6 +153,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-gemm-phase", action="store_true", help="skip the second (libplangen_diag.so) handle that times the decode step without attention")
     ap.add_argument("--diag-opt", action="append", default=[], help="MEASUREMENT ONLY: key=value for pg_diag_set_option; the whole run then uses "
                     "libplangen_diag.so and the line says so (tools/ab_loop.sh)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` block (BASELINE configs[1], [2], [4] at full length after the timed region; ~20 s)")
     ap.add_argument("--cpu-steps", type=int, default=64)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--time-stride", type=int, default=8, help="instrumented pass: time every n-th decode step")
@@ -498,6 +499,102 @@ def pipelined_pass(eng, args, cfg, B, T, ids, pad, uncond_shared, n_batches):
             "what": "pg_vq_decode of batch k on a second stream under prefill + decode loop of batch k+1; same seeds as the serial run beside it"}
 
 
+def secondary_workloads(args, cfg, device):
+    """BASELINE.json configs[1], [2] and [4] at FULL length under the driver's clock: after the timed region and never part
+    of ``value``; one warm-up + one timed step each on a fresh engine sized for the workload (the headline engine is closed first).
+      uni bs=8          prefill L=256 + 576-step CFG loop + VQ decode                                              (plangen_base.py:525-607)
+      uni_2stage bs=32  stage-1 prompt L1=128, 256 forced layout tokens (EOS suppressed), then the uni path above    (:1112-1127, :513-523)
+      mmu bs=64         SigLIP-L + aligner on 64 images, prefill of 576 + 64 embeddings per row, 256 forced tokens   (:366, :513-523)
+    Text decode (K13: 24 layers + lm_head + argmax per step) gets its own HBM roofline class: bytes per step = layer weights + lm_head (419 MB)
+    + the K/V of every row at the step's context, over the measured ms per step."""
+    import torch
+    from plangen_amd.engine import Engine
+    esz_ = 2 if args.dtype == "bf16" else 4
+    w_layers = cfg.n_layers * WEIGHT_PARAMS_LAYER * esz_
+    w_lm = cfg.vocab * cfg.hidden * esz_
+    kv_key = cfg.n_layers * 2 * cfg.n_heads * cfg.head_dim * esz_
+    NT, T = 256, cfg.img_tokens
+    g = torch.Generator().manual_seed(0)
+
+    def timed(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        return r, (time.perf_counter() - t0) * 1e3
+
+    def text_class(rows, ctx0, ms_total):
+        by = sum(w_layers + w_lm + rows * (ctx0 + t) * kv_key for t in range(NT))
+        gbs = by / (ms_total * 1e-3) / 1e9
+        return {"bound": "hbm", "ms_per_step": ms_total / NT, "algorithmic_mb_per_step": by / NT / 1e6, "achieved_gbs": gbs, "frac": gbs / HBM_PEAK_GBS,
+                "what": "per step: 24 layers of weights + lm_head once + K/V of %d rows at contexts %d..%d" % (rows, ctx0, ctx0 + NT - 1)}
+
+    out = {}
+    t_all = time.perf_counter()
+    # ---- configs[1]: uni bs=8
+    B = 8
+    e = Engine(cfg, dtype=args.dtype, max_rows=2 * B, max_prompt=256, max_new=T, max_images=B, device=device)
+    try:
+        e.init_synthetic(seed=0)
+        ids, mask = synth_prompts(B, 256, cfg.vocab, cfg.pad_id, seed=0)
+        pad = Engine.pad_len_from_mask(torch.cat([mask, torch.ones((2 * B, T), dtype=torch.int32)], 1), 256)
+        for s_ in range(2):
+            _, t_p = timed(lambda: e.prefill(ids, pad, position_mode=0))
+            toks, t_l = timed(lambda: e.decode_image_tokens(T=T, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=s_))
+            _, t_v = timed(lambda: e.vq_decode(toks))
+        tot = t_p + t_l + t_v
+        lr = loop_roofline(cfg, args.dtype, B, 256, T, pad, t_l, Engine.uncond_rows_shared(ids, pad))
+        out["uni_bs8"] = {"workload": "task_type='uni' layout2image, bs=8, L=256, 576 image tokens (BASELINE configs[1])", "images_per_s": B / tot * 1e3,
+                          "ms": {"prefill": t_p, "decode_loop": t_l, "vq_decode": t_v}, "total_ms": tot,
+                          "loop_roofline": {k: lr[k] for k in ("frac", "moved_frac", "algorithmic_gb", "moved_gb")}}
+    finally:
+        e.close()
+    # ---- configs[2]: uni_2stage bs=32
+    B, L1 = 32, 128
+    e = Engine(cfg, dtype=args.dtype, max_rows=2 * B, max_prompt=256, max_new=T, max_images=B, with_lm_head=True, device=device)
+    try:
+        e.init_synthetic(seed=0)
+        ids1 = torch.randint(10, cfg.vocab - 2048, (B, L1), generator=g).int()
+        ids2, mask2 = synth_prompts(B, 256, cfg.vocab, cfg.pad_id, seed=0)
+        pad2 = Engine.pad_len_from_mask(torch.cat([mask2, torch.ones((2 * B, T), dtype=torch.int32)], 1), 256)
+        for s_ in range(2):
+            _, t_p1 = timed(lambda: e.prefill(ids1, [0] * B, position_mode=1))
+            _, t_txt = timed(lambda: e.generate_text_greedy(NT, cfg.eos_id, min_new_tokens=NT))
+            _, t_p2 = timed(lambda: e.prefill(ids2, pad2, position_mode=0))
+            toks, t_img = timed(lambda: e.decode_image_tokens(T=T, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=s_))
+            _, t_vq = timed(lambda: e.vq_decode(toks))
+        tot = t_p1 + t_txt + t_p2 + t_img + t_vq
+        out["uni_2stage_bs32"] = {"workload": "task_type='uni_2stage', bs=32: stage-1 prompt L1=128 + 256 forced layout tokens, then L=256 + 576 image tokens + VQ decode (BASELINE configs[2])",
+                                  "images_per_s": B / tot * 1e3, "total_ms": tot,
+                                  "ms": {"prefill_stage1": t_p1, "text_decode": t_txt, "prefill_stage2": t_p2, "image_decode": t_img, "vq_decode": t_vq},
+                                  "text_tokens_per_s": B * NT / t_txt * 1e3, "text_decode_roofline": text_class(B, L1, t_txt)}
+    finally:
+        e.close()
+    # ---- configs[4]: mmu bs=64
+    B, P, Lt = 64, cfg.vit_tokens, 64
+    L = P + Lt
+    e = Engine(cfg, dtype=args.dtype, max_rows=B, max_prompt=L, max_new=NT, max_images=B, with_lm_head=True, with_vq_encoder=True, with_vision=True,
+               max_vision_images=B, device=device)
+    try:
+        e.init_synthetic(seed=0)
+        pix = (torch.rand(B, 3, cfg.vit_img, cfg.vit_img, generator=g) * 2 - 1).to(e.device)
+        txt = e.embed_tokens(torch.randint(10, cfg.vocab - 2048, (B, Lt), generator=g).int())
+        cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+        for s_ in range(2):
+            feats, t_vit = timed(lambda: e.vision_encode(pix, dtype=cdt))
+            emb = torch.cat([txt[:, :1].to(feats.dtype), feats, txt[:, 1:].to(feats.dtype)], 1).contiguous()
+            _, t_pre = timed(lambda: e.prefill_embeds(emb, [0] * B, position_mode=1))
+            _, t_txt = timed(lambda: e.generate_text_greedy(NT, cfg.eos_id, min_new_tokens=NT))
+            _, t_enc = timed(lambda: e.vq_encode(pix))
+        tot = t_vit + t_pre + t_txt
+        out["mmu_bs64"] = {"workload": "task_type='mmu', bs=64: SigLIP-L/16-384 + aligner, prefill of 640 embeddings per row, 256 forced text tokens (BASELINE configs[4])",
+                           "samples_per_s": B / tot * 1e3, "total_ms": tot, "ms": {"vision_encode": t_vit, "prefill": t_pre, "text_decode": t_txt},
+                           "vq_encode_beside_ms": t_enc, "text_tokens_per_s": B * NT / t_txt * 1e3, "text_decode_roofline": text_class(B, L, t_txt),
+                           "vision_tflops": 2 * 303e6 * P * B / (t_vit * 1e-3) / 1e12}
+    finally:
+        e.close()
+    out["wall_s"] = time.perf_counter() - t_all
+    out["what"] = "one warm-up + one timed step per workload on its own engine, after the headline's timed region; never part of `value`"
+    return out
+
+
 # ------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -508,6 +605,11 @@ def run_rank(args):
         return 2
     if args.launch_check:
         return launch_check(args, world, rank)
+
+    # Host placement BEFORE anything touches the GPU (and before torch starts its thread pools): pin this rank to the CPUs of its GPU's NUMA
+    # node, disjoint from the other local ranks' slices (plangen_amd/affinity.py; sysfs only, never execs).  Reported in the line.
+    from plangen_amd import affinity
+    placement = affinity.apply(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
 
     import torch
     import torch.distributed as dist
@@ -563,14 +665,18 @@ def run_rank(args):
     uncond_shared = Engine.uncond_rows_shared(ids.cpu(), pad)
 
     phase_events = []            # per timed step: 4 events on the launch stream (recorded asynchronously, read after the final fence)
+    enqueue_ms = []              # per timed step: host wall time of the call that enqueues the 576-step loop (~100 k launches; no sync inside)
 
     def step(seed, n_tok=T, decode_pixels=True, record=False):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
         if ev: ev[0].record()
         eng.prefill(ids, pad, position_mode=0, uncond_shared=uncond_shared)
         if ev: ev[1].record()
+        h0 = time.perf_counter()
         toks = eng.decode_image_tokens(T=n_tok, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=seed)
-        if ev: ev[2].record()
+        if ev:
+            enqueue_ms.append((time.perf_counter() - h0) * 1e3)
+            ev[2].record()
         img = eng.vq_decode(toks) if (decode_pixels and n_tok == cfg.img_tokens) else None
         if ev:
             ev[3].record()
@@ -602,6 +708,19 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = eng.timing()
+    # Did the enqueue thread stay ahead of the GPU?  (tools/host_margin.py's measure, taken inside the timed region.)  Host time to enqueue one
+    # whole decode loop against the loop's device time: margin = 1 - host / device; <= 0 means the rank is launch-bound (the queue runs dry).
+    # With several timed steps the host may be blocked by a full queue; the FIRST timed step (queue drained by the fence) is the clean sample.
+    dev_loop = [e[1].elapsed_time(e[2]) for e in phase_events]
+    host = {"enqueue_ms_first_step": enqueue_ms[0] if enqueue_ms else None, "device_loop_ms_first_step": dev_loop[0] if dev_loop else None,
+            "margin": (1.0 - enqueue_ms[0] / dev_loop[0]) if enqueue_ms and dev_loop and dev_loop[0] > 0 else None,
+            "affinity": placement}
+    host["enqueue_ahead"] = None if host["margin"] is None else bool(host["margin"] > 0.05)
+    if world > 1:
+        hosts = [None] * world
+        dist.all_gather_object(hosts, {"rank": rank, "margin": host["margin"], "enqueue_ms": host["enqueue_ms_first_step"],
+                                       "cpulist": placement.get("cpulist"), "numa_node": placement.get("numa_node"), "applied": placement.get("applied")})
+        host["ranks"] = hosts
     images = G * args.steps
     out = {
         "metric": "images/sec, 384px layout2image (576 image tokens, CFG, VQ-16 decode), bs=%d per MI355X" % B,
@@ -622,6 +741,7 @@ def run_rank(args):
         "device_gb": eng.device_bytes() / 2 ** 30,
         "rccl_ranks": dist.get_world_size() if world > 1 else 1, "dist_backend": backend,
         "rank_ms_per_step": rank_ms,
+        "host": host,
         "library": "libplangen_diag.so (MEASUREMENT BUILD: --diag-opt %s)" % " ".join(args.diag_opt) if args.diag_opt else "libplangen_hip.so",
     }
     if not args.tiny and T > 1:
@@ -667,6 +787,12 @@ def run_rank(args):
             rf.pop("_class_sums", None)
     if world > 1:
         dist.barrier()
+    if rank == 0 and world == 1 and not args.no_secondary and not args.tiny and B == 64 and T == cfg.img_tokens and not args.diag_opt:
+        eng.close()                                           # (idempotent: the GEMM-phase measurement above may have released it already)
+        try:
+            out["secondary"] = secondary_workloads(args, cfg, local)
+        except Exception as ex:                               # noqa: BLE001 -- a secondary workload must never cost the headline line
+            out["secondary"] = {"failed": repr(ex)[:400]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
         # 16 threads: measured fastest for these small torch-CPU GEMMs on the 256-core bench host
         # (ms/step: 16 thr 89, 32 thr 144, 64 thr 298, 256 thr 42 466)

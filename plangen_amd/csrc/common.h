@@ -221,6 +221,21 @@ __device__ __forceinline__ void rmsnorm_row(int m, float* __restrict__ x, const 
 __device__ __forceinline__ float rope_lo(float x0, float x1, float c, float s) { return __builtin_fmaf(x0, c, -(x1 * s)); }   // out[j]    = x0 cos - x1 sin
 __device__ __forceinline__ float rope_hi(float x0, float x1, float c, float s) { return __builtin_fmaf(x1, c, x0 * s); }      // out[j+64] = x1 cos + x0 sin
 
+// Compute units of the device the calling thread is on (cached per ordinal): the persistent GEMM sizes its grid and its tile-height cost model
+// with it instead of a literal 256.  Falls back to MI355X's 256 if the query fails.
+static inline int pg_cu_count() {
+    static int cached_[64] = {};
+    int d_ = 0;
+    (void)hipGetDevice(&d_);
+    int& c = cached_[d_ & 63];
+    if (c <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d_) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+        c = v;
+    }
+    return c;
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): set once per device the calling thread is on, result
 // checked (a process-wide "done" flag left a second GPU's handle launching without it).  One call site = one flag word, one bit
 // per device ordinal; evaluates to false when the attribute call fails (the caller falls back or lets the launch report the error).

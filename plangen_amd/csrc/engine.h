@@ -112,6 +112,8 @@ struct pg_engine {
     // ---- workspaces
     long max_tok = 0;
     float* x = nullptr; void* xn = nullptr; float* part = nullptr; long part_elems = 0, decode_part_elems = 0;
+    float* ssq_part = nullptr;        // [max_rows][8] partial sums of squares of the residual rows: the deferred-1/rms decode norm (round 6)
+    bool defer_norm = true;           // decode at 65..128 rows, bf16: norm = barrier-free elementwise pass, 1/rms applied in the consumer GEMM's epilogue
     void *qbuf = nullptr, *obuf = nullptr, *hbuf = nullptr, *hfin = nullptr, *gh_in = nullptr, *gh_mid = nullptr;
     // VQ: cur / t1 / t2 / t3 rotate through vbuf
     void* vbuf[4] = {nullptr, nullptr, nullptr, nullptr}; long vbuf_elems = 0;

@@ -147,7 +147,11 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "prefill_attn")) { h->tune.prefill_attn = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "prefill_rope_epi")) { h->prefill_rope_epi = value != 0; return PG_OK; }
     if (!strcmp(key, "prefill_res_epi")) { h->prefill_res_epi = value != 0; return PG_OK; }
-    if (!strcmp(key, "gemm256")) { h->tune.gemm256 = (int)value; return PG_OK; }
+    if (!strcmp(key, "gemm256")) {        // 0 | 1 | 4 | 5 | 6, optionally + 8 (gemm256.hip::pick_tile_height documents the encoding)
+        const int v = (int)value, base = v & 7;
+        if (value < 0 || value > 15 || (v & ~15) || !(base == 0 || base == 1 || base == 4 || base == 5 || base == 6) || (base == 0 && v != 0)) return PG_ERR_ARG;
+        h->tune.gemm256 = v; h->tune_epoch++; return PG_OK;
+    }
     if (!strcmp(key, "conv_halo")) { h->tune.conv_halo = (int)value; return PG_OK; }
     if (!strcmp(key, "vq_mid_bf16")) { h->mid_bf16 = value != 0; return PG_OK; }
     if (!strcmp(key, "vq_argmin_multi")) { h->tune.vq_argmin_multi = (int)value; return PG_OK; }

@@ -301,6 +301,7 @@ int pg_engine::create() {
     }
     TRY(dalloc(&part, (size_t)part_elems * 4));
     TRY(dalloc(&part2, (size_t)decode_part_elems * 4));
+    TRY(dalloc(&ssq_part, (size_t)cfg.max_rows * 8 * 4));
     TRY(dalloc(&d_ndec2, 64));
     HIPCHK(hipMemset(d_ndec2, 0, 64));
     TRY(dalloc(&qbuf, (size_t)max_tok * HDm * esz));

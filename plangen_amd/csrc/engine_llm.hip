@@ -51,7 +51,19 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         const Layer& ly = layers[li];
         tic(s); toc(s, TC_EMPTY, 0.0);          // an event pair around nothing: what the instrumentation itself adds to every timed launch
         tic(s);
-        launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);
+        // Deferred 1/rms (round 6; decode at 65..128 rows, bf16): the norm launch becomes a barrier-free elementwise pass (residual + xw = bf16(x . w) +
+        // 8 partial sums of squares per row) and the consumer GEMM scales its fp32 result by the row's 1/rms (kernels.h).  PG_F32 and every other
+        // row count keep rmsnorm512_kernel; layer 0 of a step has no slabs to fold in (S_pend = 0) and keeps it too.
+        bool d1 = false, d2 = false;
+        int Sq = 0;
+        if constexpr (std::is_same<T, bf16>::value) {
+            if (sk && defer_norm && Hh == 2048 && S_pend > 0 && S_pend <= 8 && slab_pend <= 0x7fffffffL && ly.wqkv_t) {
+                Sq = skinny_pick_splits(3 * HDm, Hh, M);
+                d1 = deferred_norm_ok(M, 3 * HDm, Hh, Sq) && (long)Sq * M * 3 * HDm <= part_elems;
+            }
+            if (d1) launch_rmsnorm_defer(s, x, part, S_pend, slab_pend, (const bf16*)ly.ln1, (bf16*)xn, ssq_part, M, Hh);
+        }
+        if (!d1) launch_rmsnorm<T>(s, x, part, S_pend, slab_pend, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);
         toc(s, TC_NORM, norm_bytes(S_pend));
         tic(s);
         bool qkv_fused = false;
@@ -65,6 +77,13 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
                 ge.rope.tok_row = d_tok_row; ge.rope.tok_j = d_tok_j; ge.rope.pos_off = d_pos_off;
                 ge.rope.nh = cfg.n_heads; ge.rope.slots = slots; ge.rope.max_pos = max_pos;
                 qkv_fused = gemm256_try(s, ga, (const bf16*)ly.wqkv_p, Hh, 0, ge, M, 3 * HDm, Hh, 1, 1, 0);
+            }
+        }
+        if constexpr (std::is_same<T, bf16>::value) {
+            if (d1) {
+                d1 = launch_gemm_skinny_deferred(s, (const bf16*)xn, (const bf16*)ly.wqkv_t, part, M, 3 * HDm, Hh, Sq, ssq_part, cfg.rms_eps);
+                if (d1) { S_last = Sq; slab_last = (long)M * 3 * HDm; qkv_fused = true; }
+                else launch_rmsnorm<T>(s, x, part, 0, 0, (const T*)ly.ln1, (T*)xn, M, Hh, cfg.rms_eps);   // cannot happen (one predicate); the residual is already updated: normalise it the ordinary way
             }
         }
         if (!qkv_fused) gemm_llm<T>(s, (const T*)xn, (const T*)ly.wqkv, M, 3 * HDm, Hh, sk, ly.wqkv_t);
@@ -101,13 +120,22 @@ void pg_engine::run_layers(hipStream_t s, int M, int mode, T* final_out, int32_t
         else gemm_llm<T>(s, (const T*)obuf, (const T*)ly.wo, M, Hh, HDm, sk, ly.wo_t);
         toc(s, TC_O, (double)Hh * HDm * wb);
         tic(s);
-        launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);
+        if constexpr (std::is_same<T, bf16>::value) {
+            if (sk && defer_norm && Hh == 2048 && S_last > 0 && S_last <= 8 && slab_last <= 0x7fffffffL && ly.wgu_t)
+                d2 = deferred_norm_ok(M, 2 * I, Hh, 1) && (force_swiglu || skinny_pick_splits(2 * I, Hh, M) == 1);
+            if (d2) launch_rmsnorm_defer(s, x, part, S_last, slab_last, (const bf16*)ly.ln2, (bf16*)xn, ssq_part, M, Hh);
+        }
+        if (!d2) launch_rmsnorm<T>(s, x, part, S_last, slab_last, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);
         toc(s, TC_NORM, norm_bytes(S_last));
         bool fused = false;
         tic(s);
         if constexpr (std::is_same<T, bf16>::value) {
+            if (d2) {
+                fused = launch_gemm_skinny_swiglu_deferred(s, (const bf16*)xn, (const bf16*)ly.wgu_t, (bf16*)hbuf, M, 2 * I, Hh, ssq_part, cfg.rms_eps);
+                if (!fused) launch_rmsnorm<T>(s, x, part, 0, 0, (const T*)ly.ln2, (T*)xn, M, Hh, cfg.rms_eps);   // cannot happen (one predicate); see the QKV site
+            }
             // decode: SwiGLU gate fused into the gate|up GEMM epilogue (S = 1, no slab, no extra kernel)
-            if (sk && M <= 512 && Hh % 128 == 0 && (force_swiglu || skinny_pick_splits(2 * I, Hh, M) == 1))   // fused wins at every M (B=4/8/16: -2..3 % loop time)
+            if (!fused && sk && M <= 512 && Hh % 128 == 0 && (force_swiglu || skinny_pick_splits(2 * I, Hh, M) == 1))   // fused wins at every M (B=4/8/16: -2..3 % loop time)
                 fused = launch_gemm_skinny_swiglu(s, (const bf16*)xn, (const bf16*)ly.wgu, (bf16*)hbuf, M, 2 * I, Hh, (const bf16*)ly.wgu_t);
         }
         if constexpr (std::is_same<T, bf16>::value) {

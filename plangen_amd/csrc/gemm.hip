@@ -300,19 +300,19 @@ void launch_interleave_qk(hipStream_t s, const bf16* src, bf16* dst, int nh, int
 }
 
 template <int EPI, bool TILED>
-static bool sk3_prod_tiled(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {
+static bool sk3_prod_tiled(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S, SkRowScale rsc = {}) {
     const int nck = K / SK_BK / S;
     if (nck * S * SK_BK != K || (N & 15)) return false;
     const int mrows = M < 128 ? M : 128;
-    if (mrows <= 16) return sk3_prod_nck<1, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck);
-    if (mrows <= 32) return sk3_prod_nck<2, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck);
+    if (mrows <= 16) return sk3_prod_nck<1, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck, rsc);
+    if (mrows <= 32) return sk3_prod_nck<2, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck, rsc);
     // tiled weights: 64-row M blocks for every shape (measured best at M = 128: the second reader of a
     // W tile hits L2, LDS per block halves -> more blocks per CU)
     // wide N (qkv, gate|up, gen_head at 65..128 rows): 128-column blocks of 8 waves -- the x tile is fetched and staged once per 128
     // columns instead of once per 64 (loop -11 ms at bs=64); stream_gemm bit 128 keeps the 4-wave block for A/B
     if (N % 128 == 0 && N >= 4096 && !(pg_tune->stream_gemm >= 0 && (pg_tune->stream_gemm & 128)))
-        return sk3_prod_nck<4, EPI, 8, TILED>(s, x, Wt, out, M, N, K, S, nck);
-    return sk3_prod_nck<4, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck);
+        return sk3_prod_nck<4, EPI, 8, TILED>(s, x, Wt, out, M, N, K, S, nck, rsc);
+    return sk3_prod_nck<4, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck, rsc);
 }
 
 template <int EPI>
@@ -369,6 +369,23 @@ static bool sk4_prod(hipStream_t s, const bf16* x, const bf16* Wt, float* out, i
         return sk4_nck<1, 5, 3, EPI, 4, 64>(s, x, Wt, out, M, N, K, S);
     }
     return false;
+}
+// Deferred-1/rms forms (round 6; decode, > 64 rows, wide N on the tiled copy): x = bf16(residual . w_norm), ssq = rmsnorm_defer_kernel's partial
+// sums of squares; the v3 kernel scales its fp32 result by the row's 1/rms.  False when the shape has no such instantiation (the caller then
+// runs the ordinary norm).  deferred_norm_ok() is the ONE predicate both the norm launch and the GEMM launch consult.
+bool deferred_norm_ok(int M, int N, int K, int S) {
+    const int sg = pg_tune->stream_gemm >= 0 ? pg_tune->stream_gemm : (M > 64 ? 2 : 15);
+    const int nck = S > 0 ? K / SK_BK / S : 0;
+    return M > 64 && M <= 128 && K == 2048 && N >= 4096 && (N % 128) == 0 && !(sg & 1) && !(sg & 4) && S > 0 && nck * S * SK_BK == K
+           && (nck == 1 || nck == 2 || nck == 4 || nck == 8 || nck == 16);
+}
+bool launch_gemm_skinny_deferred(hipStream_t s, const bf16* xw, const bf16* Wt, float* out, int M, int N, int K, int S, const float* ssq, float eps) {
+    if (!Wt || !ssq || !deferred_norm_ok(M, N, K, S)) return false;
+    return sk3_prod_tiled<0, true>(s, xw, Wt, out, M, N, K, S, SkRowScale{ssq, eps});
+}
+bool launch_gemm_skinny_swiglu_deferred(hipStream_t s, const bf16* xw, const bf16* Wt, bf16* h, int M, int N, int K, const float* ssq, float eps) {
+    if (!Wt || !ssq || !deferred_norm_ok(M, N, K, 1)) return false;
+    return sk3_prod_tiled<1, true>(s, xw, Wt, (float*)h, M, N, K, 1, SkRowScale{ssq, eps});
 }
 void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, const bf16* Wt) {
     if (M <= 0) return;

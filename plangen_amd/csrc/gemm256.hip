@@ -25,6 +25,16 @@
 //   RAW: the phase BEFORE a half-tile is read ends its load section with s_waitcnt vmcnt(8)
 //   (8 = 2 loads x the 4 half-tiles issued after the one needed), then the phase barriers.
 //   Both margins hold with the two wave groups running one barrier apart (below).
+//   TWO-PHASE FORM (PH == 2, the default since round 5; invariants restated in round 6 after ADVICE r5): phase A reads HB0, HA0, HB1 and
+//   stages HB1(kt+1), HA1(kt+1); phase B reads HA1 and stages HA0(kt+2), HB0(kt+2).  A slot is therefore re-staged in the phase RIGHT
+//   AFTER the one that read it (HA0 / HB0: read A(kt), staged B(kt); HA1: read B(kt), staged A(kt+1); HB1: read A(kt), staged A(kt+1)), and
+//   with the groups one barrier apart the LEADING group issues that re-stage right behind the very barrier that ends the LAGGING group's
+//   load section.  WAR rule of this form: every wave executes `s_waitcnt lgkmcnt(0)` BEFORE the barrier that ends its load section (its
+//   fragments are in registers when it arrives), so one barrier separates the last read of a slot from any global_load_lds into it.  (Round 5
+//   had the lgkmcnt(0) BEHIND that barrier: only the DMA's memory latency separated the two.  tools/dma_isa_check.py checks the new rule:
+//   a re-stage needs >= 2 barriers since the slot's last read, or 1 barrier with the read drained in front of it.)
+//   RAW of the two-phase form: phase B's load section ends with vmcnt(6) (HB1(kt+1) and everything older landed), phase A's with vmcnt(8)
+//   (HA1(kt) landed); both one full phase (two barriers) before the fragments are read.
 // * Every phase = [ds_read fragments, issue 2 global_load_lds, counted vmcnt] s_barrier
 //   [lgkmcnt(0), 16 MFMAs under s_setprio 1] s_barrier.  Waves with wr == 1 pass one extra barrier
 //   before the loop, so on every SIMD one wave is in its MFMA section while the other one is in
@@ -158,8 +168,8 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
     // barriers per MFMA: the four-phase form measured only -3.5 % when a quarter of the MFMAs of phases 3 / 4 was removed (224-row tiles), i.e. its
     // phases are bound by their fixed part (two barriers, fragment reads, staging, counted wait), not by their 16 MFMAs.
 #define G2_MFMA_SECTION2(MH, BFA, NHA, BFB, NHB)                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* WAR (round 6): fragments in registers BEFORE the barrier, see the header */ \
     g2_barrier();                                                                                           \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                                          \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                        \
@@ -394,25 +404,29 @@ static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long stride
                       const Epi<bf16>& ep, int M, int N, int K, int batch, int batch2) {
     constexpr int BM = WM * (64 + 16 * MT1), BN = WN * 64, LDS = 2 * (2 * WM * 64 * 128 + 2 * WN * 32 * 128);
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-    const int per_batch = 256 / (batch * batch2) > 8 ? 256 / (batch * batch2) : 8;   // blocks per (batch) slice: one per CU overall
+    const int ncu = pg_cu_count();
+    const int per_batch = ncu / (batch * batch2) > 8 ? ncu / (batch * batch2) : 8;   // blocks per (batch) slice: one per CU overall
     dim3 grid(ntm * ntn < per_batch ? ntm * ntn : per_batch, batch, batch2), block(512);
     auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN, ROPE, MT1, PH>;
     (void)PG_DYN_LDS(kfn, LDS);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
 }
 
-// Tile height of a plain-A launch (round 5): rounds of 256 resident blocks x rows per tile (+ a fixed per-tile share for the epilogue
+// Tile height of a plain-A launch (round 5): rounds of one resident block per CU x rows per tile (+ a fixed per-tile share for the epilogue
 // and the pipeline fill, in row equivalents), smallest wins; ties keep the taller tile.  Returns MT1 (4 / 3 / 2 = 256 / 224 / 192 rows).
+// Option encoding (the ONE place it is documented for the code; include/plangen_hip.h for callers; pg_set_option rejects anything else):
+//   gemm256 = 0 off | 1 auto tile height | 4 / 5 / 6 pin 256 / 224 / 192 rows;  + 8 = four phases per K tile instead of two.
 static int pick_tile_height(int M, int N, int batches) {
     const int pin = pg_tune->gemm256 & 7;
     if (pin >= 4) return pin == 4 ? 4 : pin == 5 ? 3 : 2;      // A/B: 4 / 5 / 6 pin 256 / 224 / 192 rows
-    if (batches != 1) return 4;
+    if (batches != 1) return 4;                                 // batched launches: launch256 gives each slice its share of the CUs, tall tiles
     const int ntn = (N + 255) / 256;
+    const int ncu = pg_cu_count();
     int best = 4; long best_cost = -1;
     for (int mt1 = 4; mt1 >= 2; --mt1) {
         const int bm = 2 * (64 + 16 * mt1);
         const long tiles = (long)((M + bm - 1) / bm) * ntn;
-        const long cost = ((tiles + 255) / 256) * (bm + 16);
+        const long cost = ((tiles + ncu - 1) / ncu) * (bm + 16);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mt1; }
     }
     return best;

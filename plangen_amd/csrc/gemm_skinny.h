@@ -12,9 +12,11 @@
 // Block epilogue of the skinny kernels: the NW waves' accumulators (MFMA C layout: lane holds
 // 4 rows x 1 column) are transposed through LDS so every lane stores 16 contiguous bytes
 // instead of 32 scattered dword stores.  smem must hold MT*16 rows x (NW*16+4) floats.
+// rs (round 6, deferred-1/rms RMSNorm): per-row scale of the block's MT*16 rows in LDS (outside the transposition tile), or nullptr.  The A operand
+// then was bf16(x . w_norm) WITHOUT the 1/rms; rs[row] = rsqrt(mean(x^2) + eps) commutes with the GEMM and is applied to the fp32 result here.
 template <int MT, int NW>
 __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)[MT], float* __restrict__ o, int M, int N,
-                                                  int mbase, int nbase, int w, int g, int lr, int tid, int wt = 0) {
+                                                  int mbase, int nbase, int w, int g, int lr, int tid, int wt = 0, const float* rs = nullptr) {
     constexpr int LD = NW * 16 + 4, NTH = NW * 64, V4 = NW * 4;        // float4 per tile row
     float* t = (float*)smem;
     __syncthreads();                                   // every wave is done reading the x tiles
@@ -27,7 +29,8 @@ __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)
         const int row = v / V4, c4 = (v % V4) * 4;
         const int m = mbase + row, n = nbase + c4;
         if (m < M && n < N) {
-            const f32x4 v4 = *(const f32x4*)(t + row * LD + c4);
+            f32x4 v4 = *(const f32x4*)(t + row * LD + c4);
+            if (rs) { const float r_ = rs[row]; v4.x *= r_; v4.y *= r_; v4.z *= r_; v4.w *= r_; }
             float* p = o + (long)m * N + n;
             // wt: write-through (sc1) -- the slab leaves this XCD's L2 while the kernel runs, not as dirty lines at the boundary
             // `s_nop 1` INSIDE the statement: hipcc does not know this is a 128-bit VMEM store, so it neither keeps the data registers
@@ -43,7 +46,7 @@ __device__ __forceinline__ void skinny_store_tile(char* smem, const f32x4 (&acc)
 // out of the transposed LDS tile; bf16 h [M, I] is written, no fp32 slab, no extra kernel.
 template <int MT, int NW>
 __device__ __forceinline__ void skinny_store_swiglu(char* smem, const f32x4 (&acc)[MT], bf16* __restrict__ h, int M, int I,
-                                                    int mbase, int nblk, int w, int g, int lr, int tid) {
+                                                    int mbase, int nblk, int w, int g, int lr, int tid, const float* rs = nullptr) {
     constexpr int LD = NW * 16 + 4, NTH = NW * 64, OC = NW * 8;        // outputs per tile row
     float* t = (float*)smem;
     __syncthreads();
@@ -57,8 +60,9 @@ __device__ __forceinline__ void skinny_store_swiglu(char* smem, const f32x4 (&ac
         const int m = mbase + row, col = nblk * OC + c2;
         if (m < M && col < I) {
             const int tc = (c2 >> 3) * 16 + (c2 & 7);                   // gate column in the tile
-            const float g0 = t[row * LD + tc], g1 = t[row * LD + tc + 1];
-            const float u0 = t[row * LD + tc + 8], u1 = t[row * LD + tc + 9];
+            const float r_ = rs ? rs[row] : 1.f;                        // deferred 1/rms of the row (x 1.0f is exact: the undeferred form keeps its bits)
+            const float g0 = t[row * LD + tc] * r_, g1 = t[row * LD + tc + 1] * r_;
+            const float u0 = t[row * LD + tc + 8] * r_, u1 = t[row * LD + tc + 9] * r_;
             const float h0 = (g0 / (1.f + expf(-g0))) * u0, h1 = (g1 / (1.f + expf(-g1))) * u1;
             *(uint32_t*)(h + (long)m * I + col) = pack_bf16x2(h0, h1);
         }
@@ -172,11 +176,19 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_kernel(const bf16* __restr
 // rows in flight (the HBM requests of chunk c+D are issued while chunk c computes), the chunk
 // loop is fully unrolled (NCK = chunks per block, compile time) so the ring is statically
 // indexed.  XDB: x tile double-buffered (2 blocks/CU at MT=8) or single-buffered (4 blocks/CU).
+constexpr int sk3_main_lds(int MT, int NW, bool XDB) {
+    const int XL = (XDB ? 2 : 1) * MT * 16 * SK_ROWB, TL = MT * 16 * (NW * 16 + 4) * 4;
+    return XL > TL ? XL : TL;
+}
 template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
-                                                               float* __restrict__ out, int M, int N, int K, int wt) {
+                                                               float* __restrict__ out, const float* __restrict__ ssq, int M, int N, int K, int wt, float eps) {
+    // ssq (round 6): deferred-1/rms RMSNorm -- x is bf16(residual . w_norm), ssq [M][8] holds 8 partial sums of squares of every residual row
+    // (rmsnorm_defer_kernel); the block turns its rows' partials into 1/rms while the first weight chunks are in flight and scales its fp32 result.
+    // nullptr: x is the normalised activation (every other caller).  4 pointers + 4 x 32 bits + eps = 52 bytes: still one preloaded kernarg block.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XB = MT * 16 * SK_ROWB, NTH = 64 * NW, BN = 16 * NW;
+    constexpr int RS_OFF = sk3_main_lds(MT, NW, XDB);                   // the row scales live behind the x tiles / the transposition tile
     constexpr int XV = (MT * 256 + NTH - 1) / NTH;                     // x vectors per thread per chunk
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
     const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
@@ -227,6 +239,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     xload(0);
+    float* const rs = ssq ? (float*)(smem + RS_OFF) : nullptr;
+    if (ssq && tid < MT * 16) {                                        // fixed summation order: the scale of a row does not depend on the block that computes it
+        const int m = mbase + tid;
+        const float* pp = ssq + (long)(m < M ? m : M - 1) * 8;
+        const f32x4 a = *(const f32x4*)pp, b = *(const f32x4*)(pp + 4);
+        rs[tid] = rsqrtf((((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) / (float)K + eps);
+    }
     xstore(0);
     __syncthreads();
 #pragma unroll
@@ -244,17 +263,18 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
             __syncthreads();
         }
     }
-    if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, bx, w, g, lr, tid);
-    else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, bx * BN, w, g, lr, tid, wt);
+    if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, bx, w, g, lr, tid, rs);
+    else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, bx * BN, w, g, lr, tid, wt, rs);
 }
+// Deferred-1/rms RMSNorm site handed down the decode GEMM dispatch (round 6): ssq [M][8] partial sums of squares + eps; null = off.
+struct SkRowScale { const float* ssq = nullptr; float eps = 0.f; };
 template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false>
-static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
-    constexpr int XL = (XDB ? 2 : 1) * MT * 16 * SK_ROWB, TL = MT * 16 * (NW * 16 + 4) * 4;
-    constexpr int LDS = XL > TL ? XL : TL;
+static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, SkRowScale rsc = {}) {
+    constexpr int LDS = sk3_main_lds(MT, NW, XDB) + MT * 16 * 4;      // + the row scales (used only with rsc.ssq)
     auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED>;
     (void)PG_DYN_LDS(kfn, LDS);
     dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
-    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, M, N, K, pg_tune->wt_store & 1);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, rsc.ssq, M, N, K, pg_tune->wt_store & 1, rsc.eps);
 }
 template <int D, bool XDB>
 static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S) {
@@ -275,15 +295,15 @@ static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out,
 
 // ---- production dispatch: v3 (W register ring depth 2, double-buffered x tile) ----
 template <int MT, int EPI, int NW = 4, bool TILED = false, int D = 2>
-static bool sk3_prod_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck) {
+static bool sk3_prod_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck, SkRowScale rsc = {}) {
     switch (nck) {
-        case 1: launch_sk3<MT, 1, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 2: launch_sk3<MT, 2, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 4: launch_sk3<MT, 4, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 8: launch_sk3<MT, 8, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 11: launch_sk3<MT, 11, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 16: launch_sk3<MT, 16, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
-        case 22: launch_sk3<MT, 22, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S); return true;
+        case 1: launch_sk3<MT, 1, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 2: launch_sk3<MT, 2, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 4: launch_sk3<MT, 4, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 8: launch_sk3<MT, 8, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 11: launch_sk3<MT, 11, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 16: launch_sk3<MT, 16, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 22: launch_sk3<MT, 22, D, true, EPI, NW, TILED>(s, x, W, out, M, N, K, S, rsc); return true;
         default: return false;
     }
 }

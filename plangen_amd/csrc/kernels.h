@@ -97,6 +97,12 @@ int skinny_pick_splits(int N, int K, int M);
 bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K, const bf16* Wt = nullptr);
 // Wt: optional tiled decode copy of W (launch_tile_weights); preferred when present
 void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, const bf16* Wt = nullptr);
+// Deferred-1/rms RMSNorm (round 6, decode at 65..128 rows, bf16): the norm launch is a barrier-free elementwise pass that writes the residual
+// stream, xw = bf16(x . w_norm) and 8 partial sums of squares per row (launch_rmsnorm_defer); the consumer GEMM applies 1/rms to its fp32 result.
+bool deferred_norm_ok(int M, int N, int K, int S);
+bool launch_gemm_skinny_deferred(hipStream_t s, const bf16* xw, const bf16* Wt, float* out, int M, int N, int K, int S, const float* ssq, float eps);
+bool launch_gemm_skinny_swiglu_deferred(hipStream_t s, const bf16* xw, const bf16* Wt, bf16* h, int M, int N, int K, const float* ssq, float eps);
+void launch_rmsnorm_defer(hipStream_t s, float* x, const float* partial, int S, long slab, const bf16* w, bf16* xw, float* ssq, int M, int H);
 void launch_tile_weights(hipStream_t s, const bf16* src, bf16* dst, int N, int K);
 // dst = Wqkv [3*nh*128, K] with the rows of every q / k head re-ordered [8 | 8] per 16-row tile (RopeEpi); v rows copied
 void launch_interleave_qk(hipStream_t s, const bf16* src, bf16* dst, int nh, int K);

@@ -39,7 +39,9 @@ template <typename T>
 void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long slab, const T* w, T* xn,
                     int M, int H, float eps, int32_t* advance) {
     if (M <= 0) return;
-    if (H == 2048) {                               // every row count (the reduction order must not depend on M: sharded == unsharded tokens); decode loop -8 ms at bs=64, -7 ms at bs=8 vs 256 threads per row
+    // rmsnorm512_kernel carries the slab stride as a 32-bit int (56-byte preloaded kernarg block): a stride that does not fit -- M x H >= 2^31,
+    // i.e. >= 2^20 rows at H = 2048, only reachable through pg_op_rmsnorm -- takes the long-stride kernel below
+    if (H == 2048 && (S == 0 || slab <= 0x7fffffffL)) {   // every row count (the reduction order must not depend on M: sharded == unsharded tokens); decode loop -8 ms at bs=64, -7 ms at bs=8 vs 256 threads per row
         // S == 0 (prefill: o / down add into the residual stream in their GEMM epilogues, 13 k rows per launch): no slab loads at all -- the
         // branch-free decode form would read every row four more times (-6 us of 34 per launch at the bench's packed batch)
         if (S == 0) hipLaunchKernelGGL((rmsnorm512_kernel<T, 0>), dim3(M), dim3(512), 0, s, x, partial, w, xn, advance, S, (int)slab, H, eps);
@@ -52,6 +54,38 @@ void launch_rmsnorm(hipStream_t s, float* x, const float* partial, int S, long s
     else if (H <= 2048) hipLaunchKernelGGL((rmsnorm_kernel<T, 2>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
     else if (H <= 4096) hipLaunchKernelGGL((rmsnorm_kernel<T, 4>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
     else hipLaunchKernelGGL((rmsnorm_kernel<T, 8>), dim3(M), dim3(256), 0, s, x, partial, S, slab, w, xn, H, eps, advance);
+}
+// Deferred-1/rms form of the decode norm (round 6; H = 2048, bf16): NO block reduction, no barrier.  Block = 256 threads = half a row, every thread
+// one f32x4 of x and of each slab (all loads up front, added in the SAME order as rmsnorm_row: the residual stream keeps its bits), stores the
+// updated residual, xw = bf16(x . w) -- the consumer GEMM's A operand WITHOUT the 1/rms -- and each WAVE leaves the sum of squares of its 256
+// columns in ssq[row][half * 4 + wave] (8 partials per row, summed in fixed order by the consumer: deterministic, no atomics).  2 M blocks instead
+// of M: twice the waves have the row's loads in flight, and the kernel's tail is a store, not a reduction.
+template <int SB>
+__global__ __launch_bounds__(256) void rmsnorm_defer_kernel(float* __restrict__ x, const float* __restrict__ partial, const bf16* __restrict__ w,
+                                                           bf16* __restrict__ xw, float* __restrict__ ssq, int S, int slab, int H) {
+    const int tid = threadIdx.x, m = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int i = half * 1024 + tid * 4;
+    float* xr = x + (long)m * H + i;
+    const u32x2 wv = *(const u32x2*)(w + i);
+    f32x4 v = *(const f32x4*)xr;
+    f32x4 t[SB];
+    const float* pp = partial + (long)m * H + i;
+    const int smax = S - 1;
+#pragma unroll
+    for (int u = 0; u < SB; ++u) t[u] = *(const f32x4*)(pp + (long)(u < smax ? u : smax) * slab);
+#pragma unroll
+    for (int u = 0; u < SB; ++u) if (u < S) v += t[u];
+    float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    *(f32x4*)xr = v;
+    u32x2 ov; ov.x = pack_bf16x2(bf16_lo(wv.x) * v.x, bf16_hi(wv.x) * v.y); ov.y = pack_bf16x2(bf16_lo(wv.y) * v.z, bf16_hi(wv.y) * v.w);
+    *(u32x2*)(xw + (long)m * H + i) = ov;
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) ssq[m * 8 + half * 4 + (tid >> 6)] = ss;
+}
+void launch_rmsnorm_defer(hipStream_t s, float* x, const float* partial, int S, long slab, const bf16* w, bf16* xw, float* ssq, int M, int H) {
+    // contract (checked by the caller through deferred_norm_ok + the engine): H == 2048, 1 <= S <= 8, slab fits 32 bits
+    if (S > 4) hipLaunchKernelGGL((rmsnorm_defer_kernel<8>), dim3(2 * M), dim3(256), 0, s, x, partial, w, xw, ssq, S, (int)slab, H);
+    else hipLaunchKernelGGL((rmsnorm_defer_kernel<4>), dim3(2 * M), dim3(256), 0, s, x, partial, w, xw, ssq, S, (int)slab, H);
 }
 template void launch_rmsnorm<float>(hipStream_t, float*, const float*, int, long, const float*, float*, int, int, float, int32_t*);
 template void launch_rmsnorm<bf16>(hipStream_t, float*, const float*, int, long, const bf16*, bf16*, int, int, float, int32_t*);

@@ -252,7 +252,9 @@ void launch_conv3x3_small(hipStream_t s, const T* x, const T* w, const float* bi
                           int B, int H, int W, int Cin, int Cout) {
     const size_t lds = (size_t)3 * 66 * (Cin * sizeof(T) + 16) + (size_t)Cout * 9 * Cin * sizeof(float);
     auto kfn = conv3x3_small_kernel<T>;
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the LDS need depends on (Cin, Cout) of the call, so the attribute is set per launch; a refused size must not be followed by a launch that
+    // would fail less legibly: the sticky error is left for the C ABI's hipGetLastError() check (-> PG_ERR_HIP), nothing is enqueued
+    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return;
     hipLaunchKernelGGL(kfn, dim3((W + 63) / 64, H, B), dim3(256), lds, s, x, w, bias, out, out_bf16, H, W, Cin, Cout);
 }
 template void launch_conv3x3_small<float>(hipStream_t, const float*, const float*, const float*, void*, int, int, int, int, int, int);

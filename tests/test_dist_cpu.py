@@ -184,3 +184,97 @@ def test_launcher_sigkill_takes_the_ranks_down_through_pdeathsig(tmp_path):
     """A SIGKILLed launcher cannot run any handler: PR_SET_PDEATHSIG in every rank covers it."""
     import signal
     _launcher_signal_case(signal.SIGKILL, tmp_path)
+
+
+# ---------------------------------------------------------------------------------------------- rank placement (plangen_amd/affinity.py)
+def _fake_sysfs(root, gpu_numa, node_cpus, cpu_nodes=2):
+    """A sysfs tree with ``cpu_nodes`` KFD CPU nodes followed by one KFD GPU node per entry of gpu_numa (render minors 128..)."""
+    kfd = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    for n in range(cpu_nodes):
+        (kfd / str(n)).mkdir(parents=True)
+        (kfd / str(n) / "properties").write_text("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+    for i, numa in enumerate(gpu_numa):
+        d = kfd / str(cpu_nodes + i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + i}\n")
+        dev = root / "class" / "drm" / f"renderD{128 + i}" / "device"
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text(f"{numa}\n")
+    for k, cl in node_cpus.items():
+        nd = root / "devices" / "system" / "node" / f"node{k}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cl + "\n")
+    return str(root)
+
+
+def test_affinity_cpulist_round_trip():
+    from plangen_amd.affinity import format_cpulist, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert format_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    assert parse_cpulist("") == [] and format_cpulist([]) == ""
+
+
+def test_affinity_plan_8_gpus_2_sockets(tmp_path):
+    """The config-4 box: 8 GPUs, 4 per socket, 2 x 64 cores with SMT siblings 128-255: every rank gets a disjoint slice of ITS GPU's node."""
+    from plangen_amd.affinity import gpu_numa_nodes, plan
+    sysfs = _fake_sysfs(tmp_path, [0, 0, 0, 0, 1, 1, 1, 1], {0: "0-63,128-191", 1: "64-127,192-255"})
+    allowed = list(range(256))
+    assert gpu_numa_nodes(sysfs, env={}) == [0, 0, 0, 0, 1, 1, 1, 1]
+    plans = [plan(r, 8, sysfs, allowed, env={}) for r in range(8)]
+    sets = [set(p["cpus"]) for p in plans]
+    assert all(len(s) == 32 for s in sets)
+    assert all(sets[a].isdisjoint(sets[b]) for a in range(8) for b in range(a + 1, 8))
+    node0, node1 = set(range(0, 64)) | set(range(128, 192)), set(range(64, 128)) | set(range(192, 256))
+    assert all(sets[r] <= node0 for r in range(4)) and all(sets[r] <= node1 for r in range(4, 8))
+    assert set().union(*sets[:4]) == node0 and set().union(*sets[4:]) == node1
+    assert [p["numa_node"] for p in plans] == [0, 0, 0, 0, 1, 1, 1, 1]
+    # a container cpuset narrower than the node is respected: only allowed CPUs are handed out
+    p = plan(5, 8, sysfs, allowed=list(range(64, 96)), env={})
+    assert set(p["cpus"]) <= set(range(64, 96)) and len(p["cpus"]) == 8
+    # ... and a cpuset with nothing on the GPU's node leaves the affinity alone instead of pinning to the wrong socket
+    assert plan(5, 8, sysfs, allowed=list(range(0, 8)), env={})["cpus"] is None
+
+
+def test_affinity_plan_visible_devices_and_degenerate_boxes(tmp_path):
+    from plangen_amd.affinity import gpu_numa_nodes, plan
+    sysfs = _fake_sysfs(tmp_path / "a", [0, 0, 1, 1], {0: "0-15", 1: "16-31"})
+    # HIP ordinal 0 is physical GPU 2 under HIP_VISIBLE_DEVICES=2,3
+    assert gpu_numa_nodes(sysfs, env={"HIP_VISIBLE_DEVICES": "2,3"}) == [1, 1]
+    p = plan(0, 2, sysfs, list(range(32)), env={"HIP_VISIBLE_DEVICES": "2,3"})
+    assert p["numa_node"] == 1 and p["cpus"] == list(range(16, 24))
+    # one GPU on a box whose firmware reports no affinity (numa_node -1, as on the 1-GPU bench boxes): nothing is pinned
+    one = _fake_sysfs(tmp_path / "b", [-1], {0: "0-7"}, cpu_nodes=1)
+    p = plan(0, 1, one, list(range(8)), env={})
+    assert p["cpus"] is None and "numa_node -1" in p["reason"]
+    # one GPU with a node: the whole node
+    one = _fake_sysfs(tmp_path / "c", [0], {0: "0-7"}, cpu_nodes=1)
+    assert plan(0, 1, one, list(range(8)), env={})["cpus"] == list(range(8))
+    # no KFD topology at all (this build container): reported, nothing pinned
+    p = plan(0, 1, str(tmp_path / "missing"), list(range(8)), env={})
+    assert p["cpus"] is None and "no KFD topology" in p["reason"]
+    # more ranks than GPUs
+    assert plan(3, 4, one, list(range(8)), env={})["cpus"] is None
+
+
+def test_affinity_apply_pins_this_process_and_reports(tmp_path):
+    """apply() in a child process (the test runner's own mask must not change): the child's mask becomes the planned slice."""
+    import json
+    import subprocess
+    import sys
+    mine = sorted(os.sched_getaffinity(0))
+    if len(mine) < 2:
+        import pytest
+        pytest.skip("needs >= 2 allowed CPUs")
+    sysfs = _fake_sysfs(tmp_path, [0, 0], {0: ",".join(str(c) for c in mine)}, cpu_nodes=1)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, os, sys; sys.path.insert(0, %r); from plangen_amd.affinity import apply; "
+            "p = apply(1, 2, %r); p['mask'] = sorted(os.sched_getaffinity(0)); print(json.dumps(p))" % (root, sysfs))
+    env = {k: v for k, v in os.environ.items() if not k.endswith("_VISIBLE_DEVICES")}       # this container hides every GPU (HIP_VISIBLE_DEVICES='')
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=env)
+    assert out.returncode == 0, out.stderr
+    p = json.loads(out.stdout.strip().splitlines()[-1])
+    half = len(mine) // 2
+    assert p["applied"] and p["mask"] == mine[half:] and p["numa_node"] == 0
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=dict(env, PG_NO_AFFINITY="1"))
+    p = json.loads(out.stdout.strip().splitlines()[-1])
+    assert not p["applied"] and p["mask"] == mine

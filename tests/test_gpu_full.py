@@ -344,7 +344,12 @@ def test_vq16_full_size_encoder_vs_reference_fixture(dtype):
     else:
         bad = idx != ref
         print(f"bf16 full-size VQ encode: {1 - bad.mean():.3f} of 576 indices equal; largest reference gap at a mismatch {gap[bad].max() if bad.any() else 0:.4f} (median gap {np.median(gap):.4f})")
-        assert bad.mean() < 0.10 and (not bad.any() or gap[bad].max() < 0.016)      # measured on MI355X: 4.5 % differ, all at reference gaps <= 0.0079 (median gap 0.024)
+        # round 6: accepted relative to the REFERENCE'S OWN encode under torch.autocast(bfloat16) on the bf16 image (plangen_base.py:530; oracle/make_golden_bf16ref.py::
+        # anchor_vq_encode, cuda policy: 91.5 % of the indices survive, largest fp32 gap at a mismatch 0.027): no more mismatches, none at a larger gap
+        import json
+        E = json.loads(str(load_golden("vq_full_encode_bf16ref.npz")["stats"]))["cuda_policy"]
+        print(f"reference-bf16 encode: {E['indices_equal_fp32']:.3f} equal, largest gap at a mismatch {E['largest_fp32_gap_at_a_mismatch']:.4f}")
+        assert int(bad.sum()) <= E["mismatches"] and (not bad.any() or gap[bad].max() <= E["largest_fp32_gap_at_a_mismatch"])
     e.close()
 
 

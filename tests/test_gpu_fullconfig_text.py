@@ -4,8 +4,9 @@
 Janus-Pro-1B width, depth (24 layers) and vocabulary (102 400, untied lm_head behind 24 layers), 6 left-padded prompts of 24-96 tokens
 (positions = mask cumsum), 24 greedy steps, at least one row stopping at EOS.  The 2-layer text fixtures (tests/test_gpu_fullvocab.py,
 test_gpu_fullwidth.py) cannot show rounding accumulated over the real depth in front of a 102 400-way argmax.
-PG_F32: ids bit-exact (stopped and un-stopped runs).  PG_BF16: the engine's ids forced into the fp32 oracle, every token within TEXT_TOL of
-the oracle's best logit (measured value printed).
+PG_F32: ids bit-exact (stopped and un-stopped runs).  PG_BF16 (round 6): accepted relative to the REFERENCE'S OWN bf16 arithmetic
+(tests/golden/generate_fullconfig_bf16ref.npz: LlamaForCausalLM under torch.autocast(bfloat16), fp32 master weights, plangen_base.py:95,360) -- logit-level
+at every prompt position, id-level through the forced-oracle protocol.
 """
 import numpy as np
 import pytest
@@ -62,8 +63,36 @@ def test_fullconfig_text_greedy_f32_matches_hf_generate():
     assert np.array_equal(probe.numpy(), g["probe"].astype(np.int64))
 
 
+def _text_ref():
+    import json
+    g = load_golden("generate_fullconfig_bf16ref.npz")
+    return g, json.loads(str(g["stats"]))
+
+
+def test_fullconfig_text_bf16_prompt_logits_vs_the_references_own_bf16():
+    """Logit-level anchor of the text path in the production dtype (round 6): next-token logits at all 417 real prompt positions (24 layers,
+    positions = mask cumsum, final norm, lm_head 2048 -> 102 400 through the decode GEMM kernels) against the fp32 reference, accepted relative to
+    E_ref = |reference-bf16 - reference-fp32| of ``LlamaForCausalLM`` under torch.autocast(bfloat16) on the same prompts: E_hip <= K x E_ref per
+    statistic and p99 |hip_bf16 - ref_bf16| <= p99 E_ref (tests/bf16ref.py).  No bound here was measured on this build."""
+    import bf16ref
+    from plangen_amd.engine import Engine
+    s = _setup()
+    e = Engine(s["cfg"], dtype="bf16", max_rows=8, max_prompt=96, max_new=32, max_images=1, with_lm_head=True)
+    e.load_state_dict(s["W"])
+    try:
+        bf16ref.check_text_prompt_logits("generate_fullconfig", e, s["W"]["language_model.lm_head.weight"], s["g"], "bf16 text path, 24 layers x vocab 102 400")
+    finally:
+        e.close()
+
+
 def test_fullconfig_text_greedy_bf16_vs_oracle_logits():
-    TEXT_TOL = 0.09                      # 1.5x the worst gap measured on MI355X in round 5: 0.060 (argmax agreement 92.4 %; the 2-layer fixtures measure 0.025-0.046)
+    """Id-level protocol (no logits cross the boundary of ``generate``): the engine's free-running bf16 ids are forced into the fp32 oracle; gap = fp32 best
+    logit - fp32 logit of the engine's token.  A flip at margin m needs two logit errors that differ by m, so the worst gap is bounded by twice the
+    reference-bf16's own worst logit error on this fixture (prompt_logits.all_columns.max of generate_fullconfig_bf16ref.npz); the reference-bf16's own
+    ids, through the same protocol, are printed beside it (worst gap 0.031, agreement 0.903 -- a max over ~14 flipped steps, not a tolerance)."""
+    import bf16ref
+    _, E = _text_ref()
+    TEXT_TOL = 2 * bf16ref.K * E["prompt_logits"]["all_columns"]["max"]
     s = _setup()
     g = s["g"]
     unused = int(g["unused_eos"])
@@ -77,7 +106,8 @@ def test_fullconfig_text_greedy_bf16_vs_oracle_logits():
     gap = lg.max(-1).values - torch.gather(lg, 2, out[..., None]).squeeze(-1)
     agree = (gap == 0).float().mean().item()
     same_as_fp32 = float((out.numpy() == g["probe"].astype(np.int64)).mean())
-    print(f"bf16 full-configuration text greedy: argmax agreement with the oracle on its own prefix {agree:.3f}, worst logit gap {gap.max().item():.4f}, "
-          f"free-running ids equal to the fp32 sequence {same_as_fp32:.3f}")
+    print(f"bf16 full-configuration text greedy: argmax agreement with the oracle on its own prefix {agree:.3f} (reference-bf16: {E['argmax_agreement_on_own_prefix']:.3f}), "
+          f"worst logit gap {gap.max().item():.4f} (reference-bf16: {E['worst_logit_gap']:.4f}; bound 2 x E_ref logit max = {TEXT_TOL:.3f}), mean gap {gap.mean().item():.5f} "
+          f"(reference-bf16: {E['gap_mean']:.5f}), free-running ids equal to the fp32 sequence {same_as_fp32:.3f} (reference-bf16: {E['free_running_ids_equal_fp32']:.3f})")
     assert gap.max().item() < TEXT_TOL, gap.max().item()
-    assert agree > 0.8
+    assert agree >= E["argmax_agreement_on_own_prefix"] - 0.03          # 144 samples: one flip = 0.7 %

@@ -59,22 +59,11 @@ def test_fulldepth_f32_tokens_bit_exact_and_logits():
 
 
 def test_fulldepth_bf16_teacher_forced():
+    """PG_BF16 accepted RELATIVE TO THE REFERENCE'S OWN bf16 arithmetic (round 6): tests/golden/sample_image_fulldepth_bf16ref.npz holds
+    E_ref = |reference-bf16 - reference-fp32| of this very loop under torch.autocast(bfloat16) with fp32 master weights (plangen_base.py:95,360;
+    oracle/make_golden_bf16ref.py: max 0.342 / p99 0.238 / p50 0.060, agreement 0.9375); tests/bf16ref.py asserts E_hip <= K x E_ref per statistic."""
+    import bf16ref
     g = _setup()["g"]
     gold = torch.from_numpy(g["tokens"])
     toks, logits = _run("bf16", force=gold.contiguous())
-    vsel = torch.from_numpy(g["vsel"]).long()
-    d = (logits[:, :, vsel] - torch.from_numpy(g["sel_logits"])).abs()
-    top_v = torch.from_numpy(g["top_v"])
-    margin = top_v[..., 0] - top_v[..., 1]
-    got = toks.t()
-    agree = got == gold.t()
-    stats = {"logit_abs_err_max": float(d.max()), "p99": float(np.percentile(d.numpy(), 99)), "p50": float(np.percentile(d.numpy(), 50)),
-             "logit_std": float(torch.from_numpy(g["sel_logits"]).std()), "agreement": float(agree.float().mean()), "margin_median": float(margin.median())}
-    print("24-layer bf16 teacher-forced:", json.dumps(stats))
-    # 24 layers of bf16 GEMM inputs under CFG weight 5 (logit std 2.7): bounds = 1.5x the values measured on MI355X (like the other full-size files)
-    assert stats["logit_abs_err_max"] < BF16_MAX and stats["p99"] < BF16_P99, stats
-    flips = (~agree) & (margin > 2 * stats["logit_abs_err_max"])
-    assert not flips.any()
-
-
-BF16_MAX, BF16_P99 = 0.40, 0.27       # 1.5x measured on MI355X (rounds 3-4): max 0.266, p99 0.177, p50 0.043 at a logit std of 2.75; agreement 93.8 %
+    bf16ref.check_image_loop("sample_image_fulldepth", logits, toks, g, "24-layer bf16 teacher-forced")

@@ -19,7 +19,7 @@ Two references:
      (2 run_pipe iterations).
 
 Tolerances are the full-width ones (tests/test_gpu_fullwidth.py): PG_F32 tokens bit-exact free-running, logits within 3e-3;
-PG_BF16 teacher-forced, |logit error| max < 0.30, p99 < 0.12, argmax equal wherever the reference's top-1 margin > 0.60.
+PG_BF16 teacher-forced: E_hip <= K x E_ref per statistic, E_ref = the reference's own autocast-bf16 error on the same images / steps (tests/bf16ref.py).
 """
 import json
 import os
@@ -29,7 +29,7 @@ import pytest
 import torch
 
 from conftest import ROOT, load_golden
-from test_gpu_fullwidth import (FULLW, LOGIT_TOL_BF16_MAX, LOGIT_TOL_BF16_P99, LOGIT_TOL_F32, _setup)
+from test_gpu_fullwidth import (FULLW, LOGIT_TOL_BF16_MAX, LOGIT_TOL_F32, _setup)
 
 pytestmark = pytest.mark.gpu
 
@@ -49,8 +49,11 @@ def _engine(dtype, max_rows):
     return _E[key]
 
 
-def _bf16_stats(logits, toks, g, sl, T):
-    """Teacher-forced bf16 statistics against fixture g restricted to images sl."""
+def _bf16_stats(logits, toks, g, sl, T, name="sample_image_fullwidth"):
+    """Teacher-forced bf16 statistics against fixture g restricted to images sl; accepted relative to the REFERENCE'S OWN bf16 arithmetic on the same
+    images and steps (tests/bf16ref.py, tests/golden/<name>_bf16ref.npz)."""
+    import bf16ref
+    bf16ref.check_image_loop(name, logits, toks, g, f"bf16 {name} images {sl.start}:{sl.stop}, {T} steps", images=sl, steps=T)
     vsel = torch.from_numpy(g["vsel"]).long().to(logits.device)
     d = (logits[:, :, vsel].cpu() - torch.from_numpy(g["sel_logits"][:T, sl])).abs()
     top_v = torch.from_numpy(g["top_v"][:T, sl])
@@ -65,10 +68,8 @@ def _bf16_stats(logits, toks, g, sl, T):
              "err_max_last_32_steps": float(d[-32:].max()),
              "teacher_forced_agreement": float(agree.float().mean()), "decisive_share": float(decisive.float().mean())}
     assert stats["logit_abs_err_max"] < LOGIT_TOL_BF16_MAX, stats
-    assert stats["p99"] < LOGIT_TOL_BF16_P99, stats
     assert torch.equal(got[decisive], gold.t()[decisive]), stats
     assert not flips.any(), stats
-    assert stats["teacher_forced_agreement"] > 0.93, stats
     return stats
 
 
@@ -160,7 +161,7 @@ def test_long_fixture_bf16_teacher_forced(graph):
         toks, logits = e.decode_image_tokens(T=T, cfg_weight=5.0, temperature=0.0, force_tokens=gold.contiguous(), return_logits=True)
     finally:
         e.set_option("use_graph", 0)
-    stats = _bf16_stats(logits, toks, g, slice(0, 8), T)
+    stats = _bf16_stats(logits, toks, g, slice(0, 8), T, name="sample_image_b8_long")
     print(f"bf16 long small-batch fixture (graph={graph}):", json.dumps(stats))
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir) and not graph:

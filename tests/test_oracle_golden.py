@@ -293,3 +293,65 @@ def test_siglip_fulldepth_fixture_is_consistent():
     assert g["features"].shape == (1, len(g["tok"]), 1024) and g["aligned"].shape == (1, len(g["tok"]), 2048)
     assert g["tok"][0] == 0 and g["tok"][-1] == 575 and np.isfinite(g["features"]).all() and np.isfinite(g["aligned"]).all()
     assert 0.9 < float(g["feat_std"]) < 1.1 and "24 blocks" in str(g["source"])
+
+
+# ---------------------------------------------------------------------------------------------- reference-bf16 anchors (round 6)
+BF16REF_IMAGE = ["sample_image_tiny", "sample_image_fullwidth", "sample_image_b8_long", "sample_image_fulldepth", "sample_image_fullconfig"]
+BF16REF_TEXT = ["generate_fullwidth", "generate_fullvocab", "generate_fullconfig"]
+
+
+def test_bf16ref_anchors_are_complete_and_consistent_with_their_fp32_fixtures():
+    """Every reference-bf16 anchor (oracle/make_golden_bf16ref.py) belongs to the fp32 fixture it names (same seeded weights), stores exact bf16 bit
+    patterns, and its stored E_ref statistics are what its stored arrays say (recomputed here from ref_bf16 - ref_fp32)."""
+    import json
+    import bf16ref
+    assert bf16ref.K <= 1.25 and bf16ref.K_MAX <= 1.25
+    for name in BF16REF_IMAGE:
+        g32, (gb, E) = load_golden(name + ".npz"), bf16ref.load(name)
+        assert abs(float(gb["wsum"]) - float(g32["wsum"])) < 1e-6 * float(g32["wsum"]), name
+        refbf = bf16ref.bf16_bits(gb["ref_bf16_sel_logits"])
+        sel = torch.from_numpy(gb["sel_steps"]).long()
+        ref32 = torch.from_numpy(g32["sel_logits"]) if "sel_logits" in g32 else torch.from_numpy(g32["logits"])[sel]
+        assert refbf.shape == ref32.shape, (name, refbf.shape, ref32.shape)
+        d = bf16ref.err_stats((refbf - ref32).abs())
+        for k in bf16ref.STATS:
+            assert abs(d[k] - E["all"][k]) <= 1e-6 + 1e-5 * E["all"][k], (name, k, d[k], E["all"][k])
+        T = g32["tokens"].shape[1]
+        assert gb["ref_bf16_tf_tokens"].shape == g32["tokens"].shape and gb["ref_bf16_at_fp32_top1"].shape[0] == T
+        agree = float((gb["ref_bf16_tf_tokens"] == g32["tokens"]).mean())
+        assert abs(agree - E["teacher_forced_agreement"]) < 1e-6, name
+        assert 0.0 < E["all"]["p50"] < E["all"]["p99"] < E["all"]["max"] and "hidden" in E and "free_running" in E
+    for name in BF16REF_TEXT:
+        g32, (gb, E) = load_golden(name + ".npz"), bf16ref.load(name)
+        assert abs(float(gb["wsum"]) - float(g32["wsum"])) < 1e-6 * float(g32["wsum"]), name
+        P = int(E["prompt_logits"]["positions"])
+        assert P == int(g32["mask"][:, :g32["ids"].shape[1]].sum()) and gb["prompt_sel_fp32"].shape == (P, len(gb["csel"]))
+        d = bf16ref.err_stats((bf16ref.bf16_bits(gb["prompt_sel_ref_bf16"]) - torch.from_numpy(gb["prompt_sel_fp32"])).abs())
+        for k in bf16ref.STATS:
+            assert abs(d[k] - E["prompt_logits"]["sel_columns"][k]) <= 1e-6 + 1e-5 * d[k], (name, k)
+        assert gb["ref_bf16_ids"].shape == g32["probe"].shape
+    for name in ("sample_image_fullconfig_vq", "vq_full_vq", "vq_full_encode", "siglip_fullwidth", "siglip_fulldepth", "prefill_long_fullwidth"):
+        E = json.loads(str(load_golden(name + "_bf16ref.npz")["stats"]))
+        assert E, name
+    # the finding the anchors record: the reference's OWN bf16 decode_code already spends more than north_star's 1e-4 pixel-MSE budget
+    vq = json.loads(str(load_golden("sample_image_fullconfig_vq_bf16ref.npz")["stats"]))
+    assert vq["cuda_policy"]["pixel_mse"] > 1e-4 and vq["cpu_policy"]["pixel_mse"] > vq["cuda_policy"]["pixel_mse"]
+
+
+def test_bf16ref_tiny_anchor_regenerates_from_the_installed_transformers(ocfg, tiny_weights):
+    """The tiny anchor re-derived HERE: the transformers-driven loop of plangen_base.py:567-607 under torch.autocast(bfloat16) with fp32 master weights,
+    teacher-forced on the fp32 fixture's tokens.  oneDNN's bf16 kernels differ between CPU generations, so the comparison is statistical: the
+    re-derived E_ref statistics within 15 % of the stored ones, argmax agreement within 0.03."""
+    import bf16ref
+    from oracle import make_golden as MG
+    from oracle.make_golden_bf16ref import autocast_sample_image
+    g32, (gb, E) = load_golden("sample_image_tiny.npz"), bf16ref.load("sample_image_tiny")
+    W = {k: v for k, v in tiny_weights.items()}
+    model = MG.hf_llama(ocfg, W)
+    ids, mask = torch.from_numpy(g32["ids"]), torch.from_numpy(g32["mask"])
+    gold = torch.from_numpy(g32["tokens"]).int()
+    tok, logits = autocast_sample_image(model, W, ids, mask, gold.shape[1], force=gold, log_every=0)
+    d = bf16ref.err_stats((logits - torch.from_numpy(g32["logits"])).abs())
+    for k in ("p50", "p99", "mean"):
+        assert abs(d[k] - E["all"][k]) < 0.15 * E["all"][k], (k, d[k], E["all"][k])
+    assert abs(float((tok == gold).float().mean()) - E["teacher_forced_agreement"]) < 0.03

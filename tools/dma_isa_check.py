@@ -79,7 +79,9 @@ def functions(lines):
             elif t.startswith(("s_cbranch", "s_branch")): ev.append(("branch", t.split()[-1]))
             elif t.startswith("global_load_lds") or (t.startswith("buffer_load") and " lds" in t): ev.append(("dma", None))
             elif t.startswith(("global_load", "buffer_load", "global_store", "buffer_store", "global_atomic", "flat_load", "flat_store")): ev.append(("vmem", None))
-            elif t.startswith("s_waitcnt") and "vmcnt(" in t: ev.append(("wait", int(re.search(r"vmcnt\((\d+)\)", t).group(1))))
+            elif t.startswith("s_waitcnt") and ("vmcnt(" in t or "lgkmcnt(0)" in t):
+                if "lgkmcnt(0)" in t: ev.append(("drain", None))          # every LDS read issued so far has returned
+                if "vmcnt(" in t: ev.append(("wait", int(re.search(r"vmcnt\((\d+)\)", t).group(1))))
             elif t.startswith("s_barrier"): ev.append(("bar", None))
             elif t.startswith("ds_read"): ev.append(("read", t.split()[0]))
             j += 1
@@ -113,6 +115,7 @@ def replay(prologue, body, spec, R=6):
     snap = [0]                      # snap[b] = VMEM ops retired when barrier b (1-based) was passed
     dma_index = []                  # VMEM issue index of every DMA instruction
     last_read_bar = {}              # tile -> number of barriers passed at its last read
+    drained_bar = {}                # tile -> number of barriers passed when an lgkmcnt(0) behind its last read was executed
     errs = []
     stream = [("p", e) for e in prologue]
     for i in range(R):
@@ -134,13 +137,30 @@ def replay(prologue, body, spec, R=6):
                 prev = tile - spec["slot_reuse"](spec["tile_cls"](tile))
                 if prev >= 0 and prev in last_read_bar and not (bars > last_read_bar[prev]):
                     errs.append(f"iteration {it}: tile {tile} staged into the slot of tile {prev} with no barrier since that tile's last read")
+                elif prev >= 0 and prev in last_read_bar and spec.get("stagger"):
+                    # wave groups run one barrier apart: a read of the LAGGING group at its local barrier count r sits between block-wide
+                    # barrier events r+1 and r+2, a re-stage by the LEADING group at its local count d behind event d.  The replay walks ONE
+                    # instruction stream (both groups run the same one), so with nb = d - r: nb >= 3 is safe; nb == 2 is safe only when the
+                    # read was drained (s_waitcnt lgkmcnt(0)) in FRONT of the barrier that follows it; nb < 2 never.
+                    nb = bars - last_read_bar[prev]
+                    if nb < 3 and not (nb == 2 and drained_bar.get(prev) == last_read_bar[prev]):
+                        errs.append(f"iteration {it}: staggered wave groups: tile {tile} staged into the slot of tile {prev} {nb} barrier(s) after its last "
+                                    f"read (one fewer for the lagging group) and that read was not drained (s_waitcnt lgkmcnt(0)) in front of its barrier")
         elif kind == "bar":
             bars += 1
             snap.append(retired)
+        elif kind == "drain":
+            for t_, b_ in last_read_bar.items():
+                if b_ == bars: drained_bar[t_] = bars              # reads of the current barrier interval are now in registers
         elif kind == "read" and it != "p":
-            tile = spec["need"](it, val)
-            if tile is None:
+            tiles = spec["need"](it, val)
+            if tiles is None:
                 continue
+            if not isinstance(tiles, (tuple, list)): tiles = (tiles,)
+            for t_ in tiles:
+                last_read_bar[t_] = bars
+                drained_bar.pop(t_, None)
+            tile = max(tiles)                                       # FIFO: the youngest of them retired => all retired
             last = (tile + 1) * g
             if last > len(dma_index):
                 errs.append(f"iteration {it}: {val} needs tile {tile} which was never issued"); continue
@@ -149,7 +169,6 @@ def replay(prologue, body, spec, R=6):
             if bars - back < 1 or snap[bars - back] < need_ops:
                 errs.append(f"iteration {it}: {val} reads tile {tile} (VMEM op #{need_ops}) but only {snap[max(bars - back, 0)]} ops were retired "
                             f"{'one barrier before' if back else 'at'} the barrier that opens this phase")
-            last_read_bar[tile] = bars
     return errs, dma_n
 
 
@@ -189,11 +208,28 @@ def gemm256_need_factory():
     return need
 
 
+def gemm256_ph2_need_factory():
+    # two-phase form (template argument PH = 2): phase A issues 16 fragment reads of HB0 + HA0 + HB1 (any order the compiler likes: they are
+    # attributed to all three half-tiles), phase B 2 x MT1 reads of HA1
+    state = {"i": -1, "n": 0}
+
+    def need(i, cls):
+        if cls != "ds_read_b128": return None
+        if state["i"] != i: state.update(i=i, n=0)
+        n = state["n"]; state["n"] += 1
+        if n < 16: return (4 * i, 4 * i + 1, 4 * i + 2)
+        return 4 * i + 3
+    return need
+
+
 SPECS = [
     ("attn_prefill", r"attn_prefill_flash2_kernel", dict(kind="fifo", g=4, need=flash2_need, tile_cls=lambda n: n & 1, slot_reuse=lambda c: 4, strict=True,
                                                          why="two barriers per tile: A(t) retires V(t), B(t) retires K(t+1)")),
-    ("gemm256", r"gemm256_kernel", dict(kind="fifo", g=2, need=None, tile_cls=lambda n: n & 3, slot_reuse=lambda c: 8, strict=True,
-                                        why="half-tiles retired by vmcnt(8) in the phase before they are read; two barriers per phase")),
+    ("gemm256", r"gemm256_kernel.*ELi2EEv", dict(kind="fifo", g=2, need="ph2", tile_cls=lambda n: n & 3, slot_reuse=lambda c: 8, strict=True, stagger=True,
+                                                 why="two-phase form: half-tiles retired by vmcnt(8) / vmcnt(6) one phase before they are read; a slot is re-staged one barrier "
+                                                     "after its last read with the read drained (lgkmcnt(0)) in front of that barrier (wave groups one barrier apart)")),
+    ("gemm256", r"gemm256_kernel", dict(kind="fifo", g=2, need=None, tile_cls=lambda n: n & 3, slot_reuse=lambda c: 8, strict=True, stagger=True,
+                                        why="four-phase form: half-tiles retired by vmcnt(8) in the phase before they are read; a slot is re-staged >= 2 phases after its last read")),
     ("diag_gemm_bw", r"gemm_bw_kernel", dict(kind="fifo", g=8, need="bw", tile_cls=lambda n: 0, slot_reuse=lambda c: 4, strict=False,
                                             why="libplangen_diag.so experiment: 4-stage ring, tile t+1 retired by vmcnt(8) + the barrier of iteration t and first read behind that barrier (weak form)")),
     ("gemm", r"gemm_sk4_kernel", dict(kind="sk4")),
@@ -240,6 +276,7 @@ def main():
                     bad += 1; report.append(f"FAIL {fname}:{short}: no main loop with DMA + LDS reads found"); continue
                 sp = dict(spec)
                 if sp["need"] is None: sp["need"] = gemm256_need_factory()
+                elif sp["need"] == "ph2": sp["need"] = gemm256_ph2_need_factory()
                 elif sp["need"] == "bw": sp["need"] = gemm_bw_need_factory()
                 errs, n = replay(pro, body, sp)
                 if errs:
