@@ -708,17 +708,28 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = eng.timing()
-    # Did the enqueue thread stay ahead of the GPU?  (tools/host_margin.py's measure, taken inside the timed region.)  Host time to enqueue one
-    # whole decode loop against the loop's device time: margin = 1 - host / device; <= 0 means the rank is launch-bound (the queue runs dry).
-    # With several timed steps the host may be blocked by a full queue; the FIRST timed step (queue drained by the fence) is the clean sample.
-    dev_loop = [e[1].elapsed_time(e[2]) for e in phase_events]
-    host = {"enqueue_ms_first_step": enqueue_ms[0] if enqueue_ms else None, "device_loop_ms_first_step": dev_loop[0] if dev_loop else None,
-            "margin": (1.0 - enqueue_ms[0] / dev_loop[0]) if enqueue_ms and dev_loop and dev_loop[0] > 0 else None,
-            "affinity": placement}
-    host["enqueue_ahead"] = None if host["margin"] is None else bool(host["margin"] > 0.05)
+    # Did the enqueue thread stay ahead of the GPU?  The enqueue call of a whole 576-step loop (~100 k launches) runs into the HIP queue's finite depth
+    # and then proceeds at the GPU's pace, so its wall time says nothing (measured round 6: 1 494 ms of host time beside 1 622 ms of device time).  The probe:
+    # after a fence, ONE 16-step decode (2.8 k launches: fits the queue) -- host time of the enqueue call against the device time of the same 16 steps.
+    # margin = 1 - host / device; <= 0 means this rank is launch-bound (the queue runs dry between kernels).  Outside the timed region.
+    host = {"affinity": placement}
+    if T > 16:
+        eng.prefill(ids, pad, position_mode=0, uncond_shared=uncond_shared)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h0 = time.perf_counter(); e0.record()
+        eng.decode_image_tokens(T=16, cfg_weight=cfg.cfg_weight, temperature=args.temperature, seed=31337)
+        h1 = time.perf_counter(); e1.record()
+        torch.cuda.synchronize()
+        dev16 = e0.elapsed_time(e1)
+        host.update({"probe": "16 decode steps enqueued behind a fence", "enqueue_ms_per_step": (h1 - h0) * 1e3 / 16, "device_ms_per_step": dev16 / 16,
+                     "margin": 1.0 - (h1 - h0) * 1e3 / max(dev16, 1e-9), "timed_loop_enqueue_call_ms": enqueue_ms[0] if enqueue_ms else None})
+        host["enqueue_ahead"] = bool(host["margin"] > 0.05)
+    else:
+        host.update({"margin": None, "enqueue_ahead": None})
     if world > 1:
         hosts = [None] * world
-        dist.all_gather_object(hosts, {"rank": rank, "margin": host["margin"], "enqueue_ms": host["enqueue_ms_first_step"],
+        dist.all_gather_object(hosts, {"rank": rank, "margin": host["margin"], "enqueue_ms_per_step": host.get("enqueue_ms_per_step"),
                                        "cpulist": placement.get("cpulist"), "numa_node": placement.get("numa_node"), "applied": placement.get("applied")})
         host["ranks"] = hosts
     images = G * args.steps

@@ -287,6 +287,57 @@ __global__ void maxdiff_kernel(const float* a, const float* b, long n, float* ou
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax((int*)out, __float_as_int(m));
 }
+// GroupNorm statistics from a GEMM / convolution EPILOGUE (conv_halo.hip, round 6: gemm256.hip) against the stand-alone statistics kernel on the tensor
+// the same launch stored: (mean, rstd) of every (image, group) must agree (both add fp32 partials in double).  plain = 1: a 1x1 convolution (kind 0,
+// K = Cin) like AttnBlock.proj_out; else 3x3 (optionally with the nearest-2x upsample).  res = 1: fp32 residual in the epilogue.  Returns the number of
+// splits the launch reported (0: the kernel that took the shape emits no partials), max |mean diff| and max relative rstd diff.
+extern "C" int pg_bench_conv_gn_check(int B, int Hi, int Wi, int Cin, int Cout, int up, int plain, int res, int gemm256_mode, int* nsplit_out, float* mean_diff, float* rstd_rel) {
+    const int Ho = plain ? Hi : (Hi << up), Wo = plain ? Wi : (Wi << up);
+    const long HW = (long)Ho * Wo, M = (long)B * HW;
+    const int K = plain ? Cin : 9 * Cin;
+    const long a_elems = (long)B * Hi * Wi * Cin;
+    bf16 *A, *Wt, *zeros; float *o0, *rsd = nullptr, *wsA, *wsB, *stA, *stB, *gam;
+    if (hipMalloc((void**)&A, a_elems * 2) != hipSuccess) return -2;
+    hipMalloc((void**)&Wt, (long)Cout * K * 2); hipMalloc((void**)&zeros, 4096); hipMemset(zeros, 0, 4096);
+    hipMalloc((void**)&o0, M * Cout * 4);
+    hipMalloc((void**)&wsA, (size_t)B * 1024 * 64 * 4); hipMalloc((void**)&wsB, (size_t)B * 1024 * 64 * 4);
+    hipMalloc((void**)&stA, (size_t)B * 64 * 4); hipMalloc((void**)&stB, (size_t)B * 64 * 4);
+    hipMalloc((void**)&gam, (size_t)Cout * 4); hipMemset(gam, 0, (size_t)Cout * 4);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, A, a_elems, 11u);
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, Wt, (long)Cout * K, 5u);
+    if (res) { hipMalloc((void**)&rsd, M * Cout * 4); bf16* tmp; hipMalloc((void**)&tmp, M * Cout * 2);
+               hipLaunchKernelGGL(fill_bf16_kernel, dim3(2048), dim3(256), 0, 0, tmp, M * Cout, 23u);
+               launch_convert<float>(0, tmp, 1, rsd, M * Cout); hipDeviceSynchronize(); hipFree(tmp); }
+    hipStream_t s; hipStreamCreate(&s);
+    GemmA ga; ga.ptr = A; ga.lda = K;
+    if (!plain) { ga.kind = 1; ga.Hi = Hi; ga.Wi = Wi; ga.Cin = Cin; ga.up = up; ga.zeros = zeros; }
+    int ns = 0;
+    ga.gn_part = wsB; ga.gn_nsplit = &ns; ga.gn_hw = plain ? (int)HW : 0;
+    GemmEpi e; e.out = o0; e.out_f32 = 1; e.ldc = Cout; e.bias_n = gam; e.residual = rsd; e.res_f32 = 1;
+    PgTune tune; tune.diag = diag_hooks(); tune.gemm256 = gemm256_mode; const PgTune* const saved = pg_tune; pg_tune = &tune;
+    hipMemsetAsync(wsB, 0xff, (size_t)B * 1024 * 64 * 4, s);                     // NaN pattern: a slot nobody writes shows up
+    launch_gemm<bf16>(s, ga, Wt, K, 0, e, (int)M, Cout, K, 1);
+    pg_tune = saved;
+    *nsplit_out = ns; *mean_diff = 0.f; *rstd_rel = 0.f;
+    int rc = 0;
+    if (ns > 0) {
+        launch_gn_finalize(s, wsB, stB, nullptr, gam, gam, B, ns, (int)HW, Cout, 1e-6f);
+        launch_gn_stats(s, o0, 0, stA, wsA, B, (int)HW, Cout, 1e-6f, nullptr, gam, gam);
+        std::vector<float> a((size_t)B * 64), b((size_t)B * 64);
+        hipStreamSynchronize(s);
+        hipMemcpy(a.data(), stA, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), stB, b.size() * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < a.size(); i += 2) {
+            const float dm = fabsf(a[i] - b[i]), dr = fabsf(a[i + 1] - b[i + 1]) / fabsf(a[i + 1]);
+            if (!(dm <= *mean_diff)) *mean_diff = dm;                              // NaN-propagating max
+            if (!(dr <= *rstd_rel)) *rstd_rel = dr;
+        }
+    }
+    hipStreamSynchronize(s);
+    if (hipGetLastError() != hipSuccess) rc = -1;
+    hipFree(A); hipFree(Wt); hipFree(zeros); hipFree(o0); if (rsd) hipFree(rsd); hipFree(wsA); hipFree(wsB); hipFree(stA); hipFree(stB); hipFree(gam);
+    hipStreamDestroy(s);
+    return rc;
+}
 extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int up, int mode, int iters, int verify,
                              float* us_out, float* maxdiff_out) {
     const bool conv = Hi > 0;

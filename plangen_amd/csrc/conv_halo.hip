@@ -342,6 +342,120 @@ __global__ __launch_bounds__(512) void conv3x3_out_halo_kernel(const bf16* __res
     }
 }
 
+// ------------------------------------------------------------------------------- norm_out + swish + conv_out in ONE pass (round 6)
+// Decoder.forward's tail (vq_model.py:210-214): h = conv_out(nonlinearity(norm_out(h))).  The unfused tail reads the fp32 skip stream (4.8 GB at
+// 64 x 384^2 x 128), writes the normalised bf16 tensor (2.4 GB), and conv_out reads that again (2.4 GB at 1.2 TB/s: its LDS-DMA fill and its MFMA
+// phase alternate on one 85 KiB patch per CU).  Here the block reads the fp32 skip stream DIRECTLY: the (4+2) x (32+2) x 128-channel patch of a
+// 4 x 32 output tile comes through registers -- y = swish(x a[b][c] + sh[b][c]) with the coefficients gn_finalize_kernel wrote, exactly
+// gn_apply_kernel's arithmetic -- is packed to bf16 and written into the same XOR-swizzled LDS layout the MFMA phase of conv3x3_out_halo_kernel
+// reads.  The NEXT tile's 13 loads per thread are issued before the current tile's MFMA phase and fly under it.  Same accumulation order (tap-major,
+// one chain per m-tile) as the unfused kernel: the two tails are bit-identical (tests/test_gpu_ops.py).  Out-of-image halo pixels are zeros of the
+// NORMALISED tensor (conv_out pads its own input).
+#define CO_TH 4
+#define CO_HP ((CO_TH + 2) * CH_HW)             // 204 halo pixels
+#define CO_NV ((CO_HP * 32 + 511) / 512)        // f32x4 vectors per thread per tile: 13
+#define CO_LDS (CO_HP * 256)
+__global__ __launch_bounds__(512) void conv3x3_out_gn_kernel(const float* __restrict__ X, const float* __restrict__ coef, const bf16* __restrict__ Wt,
+                                                            const float* __restrict__ bias, void* __restrict__ out, int out_bf16, int B, int H, int Wd,
+                                                            int Cout, int swish) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = l >> 4, lr = l & 15;
+    const int tiles_x = Wd / CH_TW, tiles_y = H / CO_TH, tiles_img = tiles_x * tiles_y;
+    const int NT = tiles_img * B, G = gridDim.x;
+    bf16x8 wf[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) {
+        wf[q] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (lr < Cout) wf[q] = *(const bf16x8*)(Wt + (long)lr * (9 * 128) + q * 32 + g * 8);
+    }
+    float bs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[j] = (g * 4 + j < Cout) ? bias[g * 4 + j] : 0.f;
+    // staging: vector v = it * 512 + tid -> halo pixel v >> 5, channels (v & 31) * 4 .. +3: the thread's channel quad is the same for every vector
+    const int c4 = tid & 31;
+    f32x4 xv[CO_NV];
+    unsigned okmask = 0;
+    auto issue = [&](int tix) __attribute__((always_inline)) {
+        const int b = tix / tiles_img, r = tix - b * tiles_img;
+        const int y0 = (r / tiles_x) * CO_TH, x0 = (r % tiles_x) * CH_TW;
+        const float* img = X + (long)b * H * Wd * 128;
+        okmask = 0;
+#pragma unroll
+        for (int it = 0; it < CO_NV; ++it) {
+            int hp = it * 16 + (tid >> 5);
+            const bool inr = hp < CO_HP;
+            hp = inr ? hp : CO_HP - 1;
+            const int hy = hp / CH_HW, hx = hp - hy * CH_HW;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            const bool ok = inr && y >= 0 && y < H && x >= 0 && x < Wd;
+            okmask |= ok ? (1u << it) : 0u;
+            const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= Wd ? Wd - 1 : x);      // clamped: the load is unconditional, the value masked
+            xv[it] = *(const f32x4*)(img + ((long)yc * Wd + xc) * 128 + c4 * 4);
+        }
+    };
+    const int orow = w >> 1, omt = w & 1;                         // wave w: output row w >> 1 of the 4 x 32 tile, pixels (w & 1) * 16 .. +15
+    const int hp0 = orow * CH_HW + omt * 16 + lr;
+    int tix = blockIdx.x;
+    if (tix < NT) issue(tix);
+    for (; tix < NT; tix += G) {
+        const int b = tix / tiles_img, r = tix - b * tiles_img;
+        const int y0 = (r / tiles_x) * CO_TH, x0 = (r % tiles_x) * CH_TW;
+        const f32x4 ca = *(const f32x4*)(coef + ((long)b * 128 + c4 * 4) * 2), cb = *(const f32x4*)(coef + ((long)b * 128 + c4 * 4) * 2 + 4);   // a0 sh0 a1 sh1 | a2 sh2 a3 sh3
+#pragma unroll
+        for (int it = 0; it < CO_NV; ++it) {
+            const int hp = it * 16 + (tid >> 5);
+            float t0 = fmaf(xv[it][0], ca[0], ca[1]), t1 = fmaf(xv[it][1], ca[2], ca[3]), t2 = fmaf(xv[it][2], cb[0], cb[1]), t3 = fmaf(xv[it][3], cb[2], cb[3]);
+            if (swish) {                                          // gn_apply_kernel's bf16-output form
+                t0 = t0 * __frcp_rn(1.f + __expf(-t0)); t1 = t1 * __frcp_rn(1.f + __expf(-t1));
+                t2 = t2 * __frcp_rn(1.f + __expf(-t2)); t3 = t3 * __frcp_rn(1.f + __expf(-t3));
+            }
+            u32x2 pk; pk.x = pack_bf16x2(t0, t1); pk.y = pack_bf16x2(t2, t3);
+            if (!((okmask >> it) & 1u)) { pk.x = 0u; pk.y = 0u; }
+            // logical 16-byte chunk j = c4 >> 1 of pixel hp lives at slot j ^ (hp & 15); this thread owns its low / high 8 bytes
+            if (hp < CO_HP) *(u32x2*)(halo + hp * 256 + ((((c4 >> 1) ^ (hp & 15))) << 4) + (c4 & 1) * 8) = pk;
+        }
+        __syncthreads();                                          // the patch is complete
+        if (tix + G < NT) issue(tix + G);                         // next tile's loads fly under this tile's MFMA phase
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int hp = hp0 + dy * CH_HW + dx;
+            const int ab = hp * 256 + (((hp & 15) ^ g) << 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 af = *(const bf16x8*)(halo + (ab ^ (q << 6)));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap * 4 + q], af, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                          // every wave is done reading: the next tile may overwrite the patch
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < Cout) {
+                    const long o = (((long)b * Cout + j) * H + y0 + orow) * Wd + x0 + omt * 16 + lr;
+                    const float v = acc[j] + bs[j];
+                    if (out_bf16) ET<bf16>::st((bf16*)out + o, v); else ((float*)out)[o] = v;
+                }
+        }
+    }
+}
+// norm_out + swish + conv_out from the fp32 skip stream; false when the shape is not the decoder tail's (the caller runs gn_apply + conv_out_halo_try)
+bool conv_out_gn_try(hipStream_t s, const float* x_f32, const float* coef, const bf16* w, const float* bias, void* out, int out_bf16,
+                     int B, int H, int Wd, int Cin, int Cout, int swish) {
+    if (!pg_tune->conv_halo || Cin != 128 || Cout > 4 || H % CO_TH || Wd % CH_TW) return false;
+    const int tiles = B * (H / CO_TH) * (Wd / CH_TW);
+    if (tiles < 64) return false;
+    auto kfn = conv3x3_out_gn_kernel;
+    if (!PG_DYN_LDS(kfn, CO_LDS)) return false;
+    hipLaunchKernelGGL(kfn, dim3(tiles < pg_cu_count() ? tiles : pg_cu_count()), dim3(512), CO_LDS, s, x_f32, coef, w, bias, out, out_bf16, B, H, Wd, Cout, swish);
+    return true;
+}
+
 bool conv_out_halo_try(hipStream_t s, const bf16* x, const bf16* w, const float* bias, const bf16* zeros, void* out, int out_bf16,
                        int B, int H, int Wd, int Cin, int Cout) {
     if (!pg_tune->conv_halo || Cin != 128 || Cout > 4 || H % CH_TH || Wd % CH_TW) return false;

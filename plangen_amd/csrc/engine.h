@@ -208,9 +208,10 @@ struct pg_engine {
     template <typename T> int vq_decode(const int32_t* codes, void* img_out, int out_dtype, int B, hipStream_t s);
     template <typename T> int vq_encode(const void* img, int img_dtype, int64_t* idx, int B, hipStream_t s);
     template <typename T> void conv3(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual, int res_f32, int B, int Hi, int Wi, int up, int stride2, int feeds_gn = -1);
-    template <typename T> void conv1(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual, int res_f32, long M);
+    template <typename T> void conv1(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual, int res_f32, long M, int gn_hw = 0);   // gn_hw > 0: the output feeds a GroupNorm (pixels per image)
     template <typename T> void resblock(hipStream_t s, const ResBlockW& r, int B, int Hs, int Ws);
     template <typename T> void attnblock(hipStream_t s, const AttnW& a, int B, int HW);
+    template <typename TI> void gn_coefs(hipStream_t s, const NormW& n, const TI* in, int B, int HW);      // statistics (conv epilogue partials or the stats kernel) -> gn_coef
     template <typename T, typename TI = float> void gn(hipStream_t s, const NormW& n, const TI* in, T* out, int B, int HW, int swish);
     int fetch_timing();
     void destroy();

@@ -154,6 +154,7 @@ int pg_set_option(pg_handle h, const char* key, int64_t value) {
     }
     if (!strcmp(key, "conv_halo")) { h->tune.conv_halo = (int)value; return PG_OK; }
     if (!strcmp(key, "vq_mid_bf16")) { h->mid_bf16 = value != 0; return PG_OK; }
+    if (!strcmp(key, "vq_tail_fused")) { h->tune.vq_tail_fused = value != 0; return PG_OK; }
     if (!strcmp(key, "vq_argmin_multi")) { h->tune.vq_argmin_multi = (int)value; return PG_OK; }
     if (!strcmp(key, "vit_attn")) { h->tune.vit_attn = (int)value; return PG_OK; }
     if (!strcmp(key, "ln_wave")) { h->tune.ln_wave = (int)value; return PG_OK; }

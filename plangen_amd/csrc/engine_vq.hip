@@ -6,12 +6,17 @@
 // conv outputs feeding a GroupNorm, shortcut outputs) are fp32; conv / GEMM inputs (GroupNorm
 // outputs, attention operands) are T.  Keeping the skip stream in fp32 removes the largest
 // bf16 error term (measured offline: 5.6e-5 of the 1e-4 pixel-MSE budget).
-template <typename T, typename TI>
-void pg_engine::gn(hipStream_t s, const NormW& n, const TI* in, T* out, int B, int HW, int swish) {
-    // statistics already produced by the convolution that wrote ``in`` (conv_halo epilogue)?
+// GroupNorm statistics of ``in`` -> per-(image, channel) affine coefficients in gn_coef (y = x a + sh)
+template <typename TI>
+void pg_engine::gn_coefs(hipStream_t s, const NormW& n, const TI* in, int B, int HW) {
+    // statistics already produced by the convolution that wrote ``in`` (conv_halo / gemm256 epilogue)?
     if (gn_part_of == (const void*)in && gn_part_n > 0 && gn_part_b == B) launch_gn_finalize(s, gn_ws, gn_stats, gn_coef, n.g, n.b, B, gn_part_n, HW, n.c, 1e-6f);
     else launch_gn_stats(s, in, sizeof(TI) == 2, gn_stats, gn_ws, B, HW, n.c, 1e-6f, gn_coef, n.g, n.b);
     gn_part_of = nullptr;
+}
+template <typename T, typename TI>
+void pg_engine::gn(hipStream_t s, const NormW& n, const TI* in, T* out, int B, int HW, int swish) {
+    gn_coefs<TI>(s, n, in, B, HW);
     launch_gn_apply<TI, T>(s, in, gn_coef, out, B, HW, n.c, swish);
 }
 template <typename T>
@@ -29,10 +34,15 @@ void pg_engine::conv3(hipStream_t s, const ConvW& cw, const T* in, void* out, in
 }
 template <typename T>
 void pg_engine::conv1(hipStream_t s, const ConvW& cw, const T* in, void* out, int out_f32, const void* residual,
-                      int res_f32, long M) {
+                      int res_f32, long M, int gn_hw) {
     GemmA a; a.ptr = in; a.lda = cw.cin;
     GemmEpi e; e.out = out; e.out_f32 = out_f32; e.ldc = cw.cout; e.bias_n = cw.b; e.residual = residual; e.res_f32 = res_f32;
+    int nsp = 0;
+    // the output feeds a GroupNorm: statistics from the GEMM's epilogue when the kernel can (round 6).  Without the request gn_ws is not written and
+    // whatever partials it holds (of the tensor a previous convolution stored) stay valid: gn_part_of is left alone.
+    if (gn_hw > 0) { gn_part_of = nullptr; a.gn_part = gn_ws; a.gn_nsplit = &nsp; a.gn_hw = gn_hw; }
     launch_gemm<T>(s, a, (const T*)cw.w, cw.cin, 0, e, (int)M, cw.cout, cw.cin, 1);
+    if (nsp > 0) { gn_part_of = out; gn_part_n = nsp; gn_part_b = (int)(M / gn_hw); }
 }
 // ResnetBlock.forward (vq_model.py:337-352) on ``cur`` (fp32); result becomes the new ``cur``.
 template <typename T>
@@ -80,7 +90,7 @@ void pg_engine::attnblock(hipStream_t s, const AttnW& a, int B, int HW) {
         GemmEpi e; e.out = ao; e.out_f32 = 0; e.ldc = C; e.strideC = (long)HW * C;
         launch_gemm<T>(s, ga, (const T*)avt, HW, (long)C * HW, e, HW, C, HW, B);
     }
-    conv1<T>(s, a.p, (const T*)ao, t2, 1, cur, 1, (long)B * HW);
+    conv1<T>(s, a.p, (const T*)ao, t2, 1, cur, 1, (long)B * HW, HW);          // the block's output is the next GroupNorm's input
     std::swap(cur, t2);
 }
 
@@ -112,11 +122,25 @@ int pg_engine::vq_decode(const int32_t* codes, void* img_out, int out_dtype, int
             side *= 2;
         }
     }
-    gn<T>(s, dec.norm_out, (const float*)cur, (T*)t1, B, side * side, 1);
-    bool co_done = false;
+    // tail (vq_model.py:210-214): conv_out(swish(norm_out(h))).  bf16: one pass over the fp32 skip stream (conv3x3_out_gn_kernel, round 6: the normalised
+    // tensor is never written; bit-identical to the unfused tail, option vq_tail_fused = 0 keeps that for A/B); otherwise gn_apply + conv_out.
+    bool co_done = false, t1_ready = false;
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (tune.vq_tail_fused && tune.conv_halo && dec.norm_out.c == 128 && dec.conv_out.cin == 128) {
+            gn_coefs<float>(s, dec.norm_out, (const float*)cur, B, side * side);
+            co_done = conv_out_gn_try(s, (const float*)cur, gn_coef, (const bf16*)dec.conv_out.w, dec.conv_out.b, img_out, out_dtype == PG_BF16, B, side, side,
+                                      dec.conv_out.cin, 3, 1);
+            if (!co_done) {       // shape not taken: the coefficients are in place, only the apply pass is missing
+                launch_gn_apply<float, T>(s, (const float*)cur, gn_coef, (T*)t1, B, side * side, dec.norm_out.c, 1);
+                t1_ready = true;
+            }
+        }
+    }
+    if (!co_done && !t1_ready) gn<T>(s, dec.norm_out, (const float*)cur, (T*)t1, B, side * side, 1);
     if constexpr (std::is_same<T, bf16>::value)
-        co_done = conv_out_halo_try(s, (const bf16*)t1, (const bf16*)dec.conv_out.w, dec.conv_out.b, (const bf16*)zeros, img_out,
-                                    out_dtype == PG_BF16, B, side, side, dec.conv_out.cin, 3);
+        if (!co_done)
+            co_done = conv_out_halo_try(s, (const bf16*)t1, (const bf16*)dec.conv_out.w, dec.conv_out.b, (const bf16*)zeros, img_out,
+                                        out_dtype == PG_BF16, B, side, side, dec.conv_out.cin, 3);
     if (!co_done)
         launch_conv3x3_small<T>(s, (const T*)t1, (const T*)dec.conv_out.w, dec.conv_out.b, img_out, out_dtype == PG_BF16, B, side, side,
                                 dec.conv_out.cin, 3);

@@ -375,6 +375,45 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                         *(uint2*)(hout + (long)row * ep.e.ldc + col) = q;
                     }
                 }
+        } else if (NMT == 8 && ep.e.gn_part && vec) {
+            // GroupNorm(32) statistics of the values being stored (round 6; conv_halo.hip does the same for the 384^2 / 192^2 levels): a wave owns two
+            // 64-row chunks x 64 columns; a chunk never straddles an image (HW % 64 == 0, checked by gemm256_try), so every (image, chunk, group)
+            // slot has exactly ONE writer -- fixed-order reduction (4 m-tiles in registers, 16 row lanes + the group's column lanes by shuffles), no
+            // atomics; gn_finalize_kernel adds an image's chunks in double.  Replaces the separate gn_stats pass over the stored tensor.
+            const int cpg = ep.e.gn_cpg, hw = ep.e.gn_hw, nsplit = hw >> 6;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mq = 0; mq < 2; ++mq) {
+                    const int mp = h * 2 + mq;
+                    int rows[8], cols[8]; f32x4 av[8], vo[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { rows[i] = em0 + (mp * 2 + (i >> 2)) * 16; cols[i] = en0 + (i & 3) * 16; av[i] = acc[mp * 2 + (i >> 2)][i & 3]; }
+                    ep.template store4_batch<8>(coff, roff, rows, cols, av, true, vo);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x4 v = vo[i];
+                        s1[i & 3] += (v[0] + v[1]) + (v[2] + v[3]);
+                        s2[i & 3] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
+                }
+                const int row0 = em0 - lr + h * 64;                    // first row of the chunk
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { s1[nt] += __shfl_xor(s1[nt], o, 64); s2[nt] += __shfl_xor(s2[nt], o, 64); }
+                    if (cpg >= 8) { s1[nt] += __shfl_xor(s1[nt], 16, 64); s2[nt] += __shfl_xor(s2[nt], 16, 64); }
+                    if (cpg >= 16) { s1[nt] += __shfl_xor(s1[nt], 32, 64); s2[nt] += __shfl_xor(s2[nt], 32, 64); }
+                    const int col = en0 + nt * 16;
+                    const bool writer = lr == 0 && (cpg == 4 || (cpg == 8 && (g & 1) == 0) || (cpg == 16 && g == 0));
+                    if (writer && row0 < M && col < N) {
+                        const int b = row0 / hw, split = (row0 - b * hw) >> 6;
+                        float* o = ep.e.gn_part + (((long)b * nsplit + split) * 32 + col / cpg) * 2;
+                        o[0] = s1[nt]; o[1] = s2[nt];
+                    }
+                }
+            }
         } else {
             // two m-tile rows (8 fragments) per batch: their bias / residual loads go out together (gemm_common.h store4_batch)
 #pragma unroll
@@ -444,10 +483,18 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
     // padding waste of the last tile row / column, and enough tiles to fill the chip
     if ((long)ntm * BM * ntn * BN > (long)M * N * 5 / 4) return false;
     if ((long)ntm * ntn * batch * batch2 < 200) return false;
-    Epi<bf16> ep{e, M, N};
+    // GroupNorm partials of the output from the epilogue (round 6): N = 32 groups of 4 / 8 / 16 channels, images of a multiple of 64 pixels (a wave's
+    // 64-row chunk then never straddles two images), dense [M][N] output, 256-row tiles (the chunk arithmetic assumes them)
+    GemmEpi eg = e;
+    const long out_hw = a.kind == 0 ? a.gn_hw : (a.kind == 2 ? (long)(a.Hi / 2) * (a.Wi / 2) : (long)(a.Hi << a.up) * (a.Wi << a.up));
+    const bool want_gn = a.gn_part && a.gn_nsplit && batch == 1 && batch2 == 1 && e.act == 0 && (N == 128 || N == 256 || N == 512) && e.ldc == N
+                         && out_hw >= 64 && (out_hw % 64) == 0 && (M % out_hw) == 0 && out_hw / 64 <= 1024 && !e.strideC
+                         && (((e.ldr ? e.ldr : e.ldc) | e.ldc) & 3) == 0;          // the kernel's vec_ok() for coff = roff = 0: the partials come out of the vector epilogue only
+    if (want_gn) { eg.gn_part = (float*)a.gn_part; eg.gn_hw = (int)out_hw; eg.gn_cpg = N / 32; *a.gn_nsplit = (int)(out_hw / 64); }
+    Epi<bf16> ep{eg, M, N};
     if (a.kind == 0) {
         PlainLoaderB<bf16> al; al.A = (const bf16*)a.ptr; al.lda = a.lda; al.M = M;
-        const int mt1 = pick_tile_height(M, N, batch * batch2);
+        const int mt1 = want_gn ? 4 : pick_tile_height(M, N, batch * batch2);
 #define G2_LAUNCH(ROPE_, MT1_, PH_) launch256<PlainLoaderB<bf16>, 2, 4, ROPE_, MT1_, PH_>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2)
         // two phases per K tile by default (round 5: +2-3 % on every prefill shape, bit-identical); gemm256 bit 3 (value 8) selects the four-phase schedule for A/B
         const bool four = (pg_tune->gemm256 & 8) != 0;

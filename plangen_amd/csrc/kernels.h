@@ -21,6 +21,7 @@ struct PgTune {
     int attn_waves = 0;                                         // 4 / 8 pin the decode-attention block size
     int attn_variant = 0;                                       // libplangen_diag.so only: which fused decode-attention form PgDiagHooks::attn_decode launches (0: production)
     int prefill_attn = 2;                                       // MFMA prefill attention: 2 = 128-query LDS-DMA / transpose-read kernel, 1 = 64-query kernel
+    int vq_tail_fused = 1;                                      // VQ decoder tail: norm_out + swish + conv_out in one pass over the fp32 skip stream (0: gn_apply + conv_out; bit-identical)
     int vq_argmin_multi = 1;                                    // VQ nearest-code search: 8 latent vectors per block (0: one per block, rounds 1-3)
     int vit_attn = 2;                                           // SigLIP attention: 2 = K / V^T of a head resident in LDS (round 4), 1 = 64-key tile kernel
     int ln_wave = 1;                                            // SigLIP LayerNorm: wave-per-row register kernel (0: generic block-per-row kernel)
@@ -46,6 +47,7 @@ struct GemmA {
     const void* zeros = nullptr;        // >= 256 B of zeros (conv halo source)
     void* gn_part = nullptr;            // optional: GroupNorm partials of the OUTPUT (kernels that support it set *gn_nsplit > 0)
     int* gn_nsplit = nullptr;
+    int gn_hw = 0;                      // pixels per image of the OUTPUT for kind == 0 launches that ask for partials (1x1 convolutions); convolutions derive it
 };
 // act == 3 (256x256 kernel, prefill QKV projection): RoPE(q), RoPE(k) and the KV-cache write straight from the accumulators.
 // W must be the [8 | 8]-interleaved copy of Wqkv (launch_interleave_qk): n-tile t of a q / k head holds rotary columns 8t..8t+7 and
@@ -70,6 +72,9 @@ struct GemmEpi {
     float scale = 1.f;
     int act = 0;                        // 0 none, 1 gelu(erf); 2 (256x256 kernel only) SwiGLU over [8 gate | 8 up] column blocks -> bf16 [M, N/2]; 3 (256x256 only) RoPE + KV write (rope)
     RopeEpi rope;
+    // 256x256 kernel only (round 6; set by gemm256_try, never by callers): GroupNorm(32) partial sums of the stored tensor, one (sum, sum of squares)
+    // per (image, 64-row chunk, group) in the layout gn_finalize_kernel reads: [B][gn_hw / 64][32][2].  gn_cpg = channels per group (4 / 8 / 16).
+    float* gn_part = nullptr; int gn_hw = 0, gn_cpg = 0;
 };
 template <typename T>
 void launch_gemm(hipStream_t s, const GemmA& a, const T* W, long ldb, long strideB,
@@ -88,6 +93,9 @@ void launch_gn_finalize(hipStream_t s, const float* ws, float* stats, float* coe
                         int nsplit, int HW, int C, float eps);
 bool conv_out_halo_try(hipStream_t s, const bf16* x, const bf16* w, const float* bias, const bf16* zeros, void* out, int out_bf16,
                        int B, int H, int Wd, int Cin, int Cout);
+// round 6: norm_out + swish + conv_out in one pass over the fp32 skip stream (coef = gn_finalize_kernel's per-(image, channel) affine coefficients)
+bool conv_out_gn_try(hipStream_t s, const float* x_f32, const float* coef, const bf16* w, const float* bias, void* out, int out_bf16,
+                     int B, int H, int Wd, int Cin, int Cout, int swish);
 
 // Skinny weight-streaming GEMM (decode): x [M,K] bf16 (M <= 128 per launch block-row),
 // W [N,K] bf16, out fp32 [S,M,N] split-K partial slabs (consumer kernels reduce over S).

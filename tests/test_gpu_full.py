@@ -65,6 +65,33 @@ def test_vq16_full_size_vs_reference_fixture(dtype):
     e.close()
 
 
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_vq16_fused_tail_equals_groupnorm_apply_plus_conv_out(out_dtype):
+    """Round 6: the decoder tail conv_out(swish(norm_out(h))) (vq_model.py:210-214) as ONE pass over the fp32 skip stream (conv3x3_out_gn_kernel:
+    GroupNorm coefficients + swish applied while the 4 x 32 halo patch is staged, the normalised tensor never written) against the unfused tail
+    (gn_apply pass + conv3x3_out_halo_kernel; option vq_tail_fused = 0) on 3 seeded images at full size: same arithmetic, same accumulation
+    order -> identical pixels; also across a second run (no stale halo between persistent tiles)."""
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    ocfg = R.OracleCfg(n_layers=0, vocab=8)
+    W = R.make_weights(ocfg, seed=2, with_lm_head=False)
+    cfg = PlanGenConfig(n_layers=0, vocab=8)
+    e = Engine(cfg, dtype="bf16", max_rows=2, max_prompt=1, max_new=1, max_images=3)
+    e.load_state_dict(W)
+    try:
+        g = torch.Generator().manual_seed(5)
+        codes = torch.randint(0, cfg.img_vocab, (3, cfg.img_tokens), generator=g).int()
+        outs = []
+        for fused in (1, 0, 1):
+            e.set_option("vq_tail_fused", fused)
+            outs.append(e.vq_decode(codes, dtype=out_dtype).cpu())
+        assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().std()) > 0.05
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        e.set_option("vq_tail_fused", 1)
+        e.close()
+
+
 def test_batch_invariance_and_pad_skipping():
     e = full_engine()
     L, T = 48, 12

@@ -92,7 +92,7 @@ def test_fullconfig_text_greedy_bf16_vs_oracle_logits():
     ids, through the same protocol, are printed beside it (worst gap 0.031, agreement 0.903 -- a max over ~14 flipped steps, not a tolerance)."""
     import bf16ref
     _, E = _text_ref()
-    TEXT_TOL = 2 * bf16ref.K * E["prompt_logits"]["all_columns"]["max"]
+    TEXT_TOL = 2 * bf16ref.K_MAX * E["prompt_logits"]["all_columns"]["max"]
     s = _setup()
     g = s["g"]
     unused = int(g["unused_eos"])

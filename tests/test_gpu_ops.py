@@ -374,3 +374,29 @@ def test_fused_norm_producer_experiment_matches_the_production_pair(M, N, K, S):
     bad = (C.c_uint * 4)()
     assert lib.pg_bench_fused_norm(M, N, K, S, 20, C.byref(a), C.byref(b), C.byref(c), bad) == 0
     assert (bad[0], bad[1], bad[2]) == (0, 0, 0), list(bad)
+
+
+@pytest.mark.parametrize("B,Hi,Cin,Cout,up,plain,res", [
+    (48, 24, 512, 512, 0, 0, 1),    # 24^2: HW = 576 = 9 x 64 (a 256-row tile straddles images; 64-row chunks do not), 16 channels per group, 216 tiles
+    (48, 24, 512, 512, 0, 1, 1),    # 1x1 (AttnBlock.proj_out, vq_model.py:388) with the fp32 residual
+    (24, 48, 512, 256, 0, 0, 0),    # 8 channels per group
+    (12, 24, 512, 512, 1, 0, 0),    # nearest-2x upsample folded into the loader (vq_model.py:417-427): output 48^2
+    (6, 96, 256, 256, 0, 0, 1),     # 96^2, Cin 256
+])
+def test_gemm256_epilogue_groupnorm_statistics_match_the_statistics_kernel(B, Hi, Cin, Cout, up, plain, res):
+    """Round 6: the 256x256 kernel's convolutions emit the GroupNorm(32) partial sums of the tensor they store (as the halo
+    kernel does), which deletes the separate gn_stats pass.  (mean, rstd) of every (image, group) from those partials must equal the statistics
+    kernel's on the stored tensor; a slot nobody wrote would surface as NaN (the workspace is pre-filled with 0xff)."""
+    import ctypes as C
+    from plangen_amd import _lib
+    lib = _lib.load_diag()
+    lib.pg_bench_conv_gn_check.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    ns, dm, dr = C.c_int(0), C.c_float(0), C.c_float(0)
+    assert lib.pg_bench_conv_gn_check(B, Hi, Hi, Cin, Cout, up, plain, res, 1, C.byref(ns), C.byref(dm), C.byref(dr)) == 0
+    hw = (Hi << (0 if plain else up)) ** 2
+    assert ns.value == hw // 64, (ns.value, hw)                     # the 256x256 kernel took the shape and reported one split per 64-row chunk
+    print(f"epilogue GroupNorm statistics: {ns.value} splits per image, max |mean diff| {dm.value:.2e}, max rel rstd diff {dr.value:.2e}")
+    assert dm.value < 2e-5 and dr.value < 2e-5, (dm.value, dr.value)
+    # the 128x128 kernel emits no partials: the caller then runs the statistics kernel (nsplit 0)
+    assert lib.pg_bench_conv_gn_check(B, Hi, Hi, Cin, Cout, up, plain, res, 0, C.byref(ns), C.byref(dm), C.byref(dr)) == 0
+    assert ns.value == 0

@@ -105,14 +105,15 @@ def test_product_library_exports_nothing_but_the_header():
 
 
 def test_product_option_table_is_small_and_has_no_result_changing_switch():
-    """pg_set_option of the product: <= 20 keys, none of the measurement-only switches; they exist only behind pg_diag_set_option."""
+    """pg_set_option of the product: <= 21 keys (round 6 added vq_tail_fused, a bit-identical A/B fallback), none of the measurement-only or
+    rounding-changing switches (skip_attn, attn_variant, defer_norm); those exist only behind pg_diag_set_option."""
     api = open(os.path.join(ROOT, "plangen_amd", "csrc", "engine_api.hip")).read()
     body = api[api.index("int pg_set_option("):api.index("int64_t pg_device_bytes(")]
     keys = re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', body)
-    assert len(keys) == len(set(keys)) and 10 <= len(keys) <= 20, keys
+    assert len(keys) == len(set(keys)) and 10 <= len(keys) <= 21, keys
     diag_src = open(os.path.join(ROOT, "plangen_amd", "csrc", "diag_api.hip")).read()
     diag_keys = set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', diag_src))
-    for k in ("skip_attn", "attn_variant"):
+    for k in ("skip_attn", "attn_variant", "defer_norm"):
         assert k not in keys and k in diag_keys
     for gone in ("cu_split", "mall_prefetch", "pf_blocks", "attn_pair", "lpt_snake", "gn_fuse"):
         assert gone not in keys and gone not in diag_keys
