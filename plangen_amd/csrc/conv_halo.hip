@@ -378,36 +378,42 @@ __global__ __launch_bounds__(512) void conv3x3_out_gn_kernel(const float* __rest
     const int c4 = tid & 31;
     f32x4 xv[CO_NV];
     unsigned okmask = 0;
-    auto issue = [&](int tix) __attribute__((always_inline)) {
+    // address + in-image flag of vector ``it`` of tile ``tix`` (clamped: the load is unconditional, the value masked)
+    auto src_of = [&](int tix, int it, bool& ok) __attribute__((always_inline)) -> const f32x4* {
         const int b = tix / tiles_img, r = tix - b * tiles_img;
         const int y0 = (r / tiles_x) * CO_TH, x0 = (r % tiles_x) * CH_TW;
-        const float* img = X + (long)b * H * Wd * 128;
-        okmask = 0;
-#pragma unroll
-        for (int it = 0; it < CO_NV; ++it) {
-            int hp = it * 16 + (tid >> 5);
-            const bool inr = hp < CO_HP;
-            hp = inr ? hp : CO_HP - 1;
-            const int hy = hp / CH_HW, hx = hp - hy * CH_HW;
-            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-            const bool ok = inr && y >= 0 && y < H && x >= 0 && x < Wd;
-            okmask |= ok ? (1u << it) : 0u;
-            const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= Wd ? Wd - 1 : x);      // clamped: the load is unconditional, the value masked
-            xv[it] = *(const f32x4*)(img + ((long)yc * Wd + xc) * 128 + c4 * 4);
-        }
+        int hp = it * 16 + (tid >> 5);
+        const bool inr = hp < CO_HP;
+        hp = inr ? hp : CO_HP - 1;
+        const int hy = hp / CH_HW, hx = hp - hy * CH_HW;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        ok = inr && y >= 0 && y < H && x >= 0 && x < Wd;
+        const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= Wd ? Wd - 1 : x);
+        return (const f32x4*)(X + (long)b * H * Wd * 128 + ((long)yc * Wd + xc) * 128 + c4 * 4);
     };
     const int orow = w >> 1, omt = w & 1;                         // wave w: output row w >> 1 of the 4 x 32 tile, pixels (w & 1) * 16 .. +15
     const int hp0 = orow * CH_HW + omt * 16 + lr;
     int tix = blockIdx.x;
-    if (tix < NT) issue(tix);
+    if (tix < NT) {
+#pragma unroll
+        for (int it = 0; it < CO_NV; ++it) { bool ok; xv[it] = *src_of(tix, it, ok); okmask |= ok ? (1u << it) : 0u; }
+    }
     for (; tix < NT; tix += G) {
         const int b = tix / tiles_img, r = tix - b * tiles_img;
         const int y0 = (r / tiles_x) * CO_TH, x0 = (r % tiles_x) * CH_TW;
         const f32x4 ca = *(const f32x4*)(coef + ((long)b * 128 + c4 * 4) * 2), cb = *(const f32x4*)(coef + ((long)b * 128 + c4 * 4) * 2 + 4);   // a0 sh0 a1 sh1 | a2 sh2 a3 sh3
+        const bool more = tix + G < NT;
+        const int tnext = more ? tix + G : tix;
+        unsigned oknext = 0;
+        // vector by vector: normalise + swish + pack, then the SAME register is re-armed with the next tile's vector (its load flies under the rest of
+        // this loop, the MFMA phase and the stores), then the packed value goes to LDS.  In-order returns: the next tile consumes xv[0] first.
 #pragma unroll
         for (int it = 0; it < CO_NV; ++it) {
             const int hp = it * 16 + (tid >> 5);
             float t0 = fmaf(xv[it][0], ca[0], ca[1]), t1 = fmaf(xv[it][1], ca[2], ca[3]), t2 = fmaf(xv[it][2], cb[0], cb[1]), t3 = fmaf(xv[it][3], cb[2], cb[3]);
+            bool okn;
+            const f32x4* nsrc = src_of(tnext, it, okn);
+            xv[it] = *nsrc; oknext |= okn ? (1u << it) : 0u;      // unconditional (the last tile re-reads itself and drops it): a conditional load costs a vmcnt(0) at the join
             if (swish) {                                          // gn_apply_kernel's bf16-output form
                 t0 = t0 * __frcp_rn(1.f + __expf(-t0)); t1 = t1 * __frcp_rn(1.f + __expf(-t1));
                 t2 = t2 * __frcp_rn(1.f + __expf(-t2)); t3 = t3 * __frcp_rn(1.f + __expf(-t3));
@@ -417,8 +423,8 @@ __global__ __launch_bounds__(512) void conv3x3_out_gn_kernel(const float* __rest
             // logical 16-byte chunk j = c4 >> 1 of pixel hp lives at slot j ^ (hp & 15); this thread owns its low / high 8 bytes
             if (hp < CO_HP) *(u32x2*)(halo + hp * 256 + ((((c4 >> 1) ^ (hp & 15))) << 4) + (c4 & 1) * 8) = pk;
         }
+        okmask = oknext;
         __syncthreads();                                          // the patch is complete
-        if (tix + G < NT) issue(tix + G);                         // next tile's loads fly under this tile's MFMA phase
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {

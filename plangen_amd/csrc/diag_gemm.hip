@@ -52,12 +52,27 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 310: return sk4_nck<4, 4, 3, 4, 2, 64 | 4096>(s, x, W, out, M, N, K, S) ? 128 : 0;  // rotation swizzle instead of XOR
         case 308: return sk4_nck<4, 4, 3, 4, 2, 64 | 1024>(s, x, W, out, M, N, K, S) ? 128 : 0;  // wave w issues pieces w, w+4, w+8, w+12
         case 309: return sk4_nck<4, 4, 3, 4, 2, 64 | 2048>(s, x, W, out, M, N, K, S) ? 128 : 0;  // LDS row placement permuted (rows ^ 12 within a 16-row group)
+        // round 6: what the o_proj launch (5.2 us for 8.4 MB) is made of -- the production block (variant 300) against an empty kernel of
+        // the same geometry, the weight stream alone, and the kernel without its stores / without its x tile (tools/launch_floor.py)
+        case 320: return sk4_nck<4, 4, 3, 4, 2, 64 | 8192>(s, x, W, out, M, N, K, S) ? 128 : 0;     // empty kernel, same grid / block / LDS / kernarg block
+        case 321: return sk4_nck<4, 4, 3, 4, 2, 64 | 7>(s, x, W, out, M, N, K, S) ? 128 : 0;        // W stream only (no x DMA / barriers, no MFMA, no stores)
+        case 322: return sk4_nck<4, 4, 3, 4, 2, 64 | 4>(s, x, W, out, M, N, K, S) ? 128 : 0;        // no stores
+        case 323: return sk4_nck<4, 4, 3, 4, 2, 64 | 1>(s, x, W, out, M, N, K, S) ? 128 : 0;        // no x tile
+        case 324: return sk4_nck<4, 4, 3, 4, 2, 64 | 2>(s, x, W, out, M, N, K, S) ? 128 : 0;        // no MFMA
         case 307: return sk4_nck<2, 4, 3, 4, 4, 64>(s, x, W, out, M, N, K, S) ? 128 : 0;         // 32-row blocks (two pieces per wave)
         // round 4: W register-ring depth of the wide-N production block (64 rows x 128 columns, 8 waves, tiled W) -- bytes in flight per block
         case 400: return sk3_prod_nck<4, 0, 8, true, 2>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;
         case 401: return sk3_prod_nck<4, 0, 8, true, 3>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;
         case 402: return sk3_prod_nck<4, 0, 8, true, 4>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;
         case 403: return sk3_prod_nck<4, 0, 8, true, 6>(s, x, W, out, M, N, K, S, K / SK_BK / S) ? 128 : 0;
+        // round 6: the bs=64 PRODUCTION wide-N blocks (64 rows x 128 columns, 8 waves, tiled W, ring 2) with per-wave cycle stamps
+        // (tools/sk3_profile.py): 500 gate|up + SwiGLU (S = 1, 16 chunks), 501 qkv (S = 2, 8 chunks), 502 / 503 the same with a ring of 4
+        case 500: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 8, true, true>(s, x, W, out, M, N, K, S, SkRowScale{(const float*)g_sk4_prof, 0.f}); return 128;
+        case 501: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 2, true, 0, 8, true, true>(s, x, W, out, M, N, K, S, SkRowScale{(const float*)g_sk4_prof, 0.f}); return 128;
+        case 502: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 4, true, 1, 8, true, true>(s, x, W, out, M, N, K, S, SkRowScale{(const float*)g_sk4_prof, 0.f}); return 128;
+        // round 6: v5 (n-tile pairs x two K halves, x by LDS-DMA): 510 gate|up + SwiGLU (S = 1), 511 fp32 slabs (qkv S = 2, gen_head / lm_head S = 1)
+        case 510: return sk5_try<3>(s, x, W, out, M, N, K, S) ? 128 : 0;
+        case 511: return sk5_try<4>(s, x, W, out, M, N, K, S) ? 128 : 0;
         case 121: return sk4_nck<8, 3, 8, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // deep W ring, direct 16-byte stores
         case 123: return sk4_nck<8, 3, 3, 2, 1>(s, x, W, out, M, N, K, S) ? 128 : 0;     // shallow W ring, direct stores
         default: return 0;

@@ -373,33 +373,45 @@ static bool sk4_prod(hipStream_t s, const bf16* x, const bf16* Wt, float* out, i
 // Deferred-1/rms forms (round 6; decode, > 64 rows, wide N on the tiled copy): x = bf16(residual . w_norm), ssq = rmsnorm_defer_kernel's partial
 // sums of squares; the v3 kernel scales its fp32 result by the row's 1/rms.  False when the shape has no such instantiation (the caller then
 // runs the ordinary norm).  deferred_norm_ok() is the ONE predicate both the norm launch and the GEMM launch consult.
+// v5 takes the wide-N GEMMs at 65..128 rows whose block K range is 8 or 16 chunks (qkv at S = 2, gate|up / gen_head / lm_head at S = 1)
+static bool sk5_shape(int M, int N, int K, int S) {
+    const int nck = S > 0 ? K / SK_BK / S : 0;
+    return pg_tune->sk5 && M > 64 && M <= 128 && N >= 4096 && (N % 128) == 0 && S > 0 && nck * S * SK_BK == K && (nck == 8 || nck == 16);
+}
 bool deferred_norm_ok(int M, int N, int K, int S) {
+    if (K != 2048) return false;
+    if (sk5_shape(M, N, K, S)) return true;
     const int sg = pg_tune->stream_gemm >= 0 ? pg_tune->stream_gemm : (M > 64 ? 2 : 15);
     const int nck = S > 0 ? K / SK_BK / S : 0;
-    return M > 64 && M <= 128 && K == 2048 && N >= 4096 && (N % 128) == 0 && !(sg & 1) && !(sg & 4) && S > 0 && nck * S * SK_BK == K
+    return M > 64 && M <= 128 && N >= 4096 && (N % 128) == 0 && !(sg & 1) && !(sg & 4) && S > 0 && nck * S * SK_BK == K
            && (nck == 1 || nck == 2 || nck == 4 || nck == 8 || nck == 16);
 }
 bool launch_gemm_skinny_deferred(hipStream_t s, const bf16* xw, const bf16* Wt, float* out, int M, int N, int K, int S, const float* ssq, float eps) {
     if (!Wt || !ssq || !deferred_norm_ok(M, N, K, S)) return false;
+    if (sk5_shape(M, N, K, S)) return sk5_try<4>(s, xw, Wt, out, M, N, K, S, SkRowScale{ssq, eps});
     return sk3_prod_tiled<0, true>(s, xw, Wt, out, M, N, K, S, SkRowScale{ssq, eps});
 }
 bool launch_gemm_skinny_swiglu_deferred(hipStream_t s, const bf16* xw, const bf16* Wt, bf16* h, int M, int N, int K, const float* ssq, float eps) {
     if (!Wt || !ssq || !deferred_norm_ok(M, N, K, 1)) return false;
+    if (sk5_shape(M, N, K, 1)) return sk5_try<3>(s, xw, Wt, (float*)h, M, N, K, 1, SkRowScale{ssq, eps});
     return sk3_prod_tiled<1, true>(s, xw, Wt, (float*)h, M, N, K, 1, SkRowScale{ssq, eps});
 }
 void launch_gemm_skinny(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, const bf16* Wt) {
     if (M <= 0) return;
+    if (Wt && sk5_shape(M, N, K, S) && sk5_try<4>(s, x, Wt, out, M, N, K, S)) return;
     if (sk4_prod<4>(s, x, Wt, out, M, N, K, S)) return;
     if (Wt && sk3_prod_tiled<0, true>(s, x, Wt, out, M, N, K, S)) return;
     if (!sk3_prod<0>(s, x, W, out, M, N, K, S)) launch_gemm_skinny_v1(s, x, W, out, M, N, K, S);
 }
 bool launch_gemm_skinny_tiled_only(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S) {      // the production dispatch on the tiled copy alone (diag: verification against v1)
+    if (sk5_shape(M, N, K, S) && sk5_try<4>(s, x, Wt, out, M, N, K, S)) return true;
     return sk4_prod<4>(s, x, Wt, out, M, N, K, S) || sk3_prod_tiled<0, true>(s, x, Wt, out, M, N, K, S);
 }
 // gate|up GEMM with the SwiGLU gate fused (S = 1): h bf16 [M, N/2].  Returns false when the
 // shape has no fused instantiation (caller falls back to slabs + silu_mul kernel).
 bool launch_gemm_skinny_swiglu(hipStream_t s, const bf16* x, const bf16* W, bf16* h, int M, int N, int K, const bf16* Wt) {
     if (M <= 0) return true;
+    if (Wt && sk5_shape(M, N, K, 1) && sk5_try<3>(s, x, Wt, (float*)h, M, N, K, 1)) return true;
     if (sk4_prod<3>(s, x, Wt, (float*)h, M, N, K, 1)) return true;
     if (Wt && sk3_prod_tiled<1, true>(s, x, Wt, (float*)h, M, N, K, 1)) return true;
     return sk3_prod<1>(s, x, W, (float*)h, M, N, K, 1);

@@ -180,15 +180,21 @@ constexpr int sk3_main_lds(int MT, int NW, bool XDB) {
     const int XL = (XDB ? 2 : 1) * MT * 16 * SK_ROWB, TL = MT * 16 * (NW * 16 + 4) * 4;
     return XL > TL ? XL : TL;
 }
-template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false>
+template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false, bool PROF = false>      // PROF (libplangen_diag.so only): per-wave cycle stamps through the ssq pointer
 __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
-                                                               float* __restrict__ out, const float* __restrict__ ssq, int M, int N, int K, int wt, float eps) {
+                                                               float* __restrict__ out, const float* __restrict__ ssq_, int M, int N, int K, int wt, float eps) {
     // ssq (round 6): deferred-1/rms RMSNorm -- x is bf16(residual . w_norm), ssq [M][8] holds 8 partial sums of squares of every residual row
     // (rmsnorm_defer_kernel); the block turns its rows' partials into 1/rms while the first weight chunks are in flight and scales its fp32 result.
     // nullptr: x is the normalised activation (every other caller).  4 pointers + 4 x 32 bits + eps = 52 bytes: still one preloaded kernarg block.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XB = MT * 16 * SK_ROWB, NTH = 64 * NW, BN = 16 * NW;
     constexpr int RS_OFF = sk3_main_lds(MT, NW, XDB);                   // the row scales live behind the x tiles / the transposition tile
+    const float* const ssq = PROF ? nullptr : ssq_;
+    // PROF: 64 stamp slots per wave, wave index = linear block index * NW + wave (tools/sk3_profile.py)
+    int pslot = 0;
+    unsigned long long* pw = PROF && ssq_ ? (unsigned long long*)ssq_ + ((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + (threadIdx.x >> 6)) * 64 : nullptr;
+    auto stamp = [&]() { if constexpr (PROF) { if (pw && (threadIdx.x & 63) == 0 && pslot < 64) pw[pslot] = __builtin_readcyclecounter(); ++pslot; } };
+    stamp();                                                            // 0: wave start
     constexpr int XV = (MT * 256 + NTH - 1) / NTH;                     // x vectors per thread per chunk
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, lr = l & 15;
     const int split = blockIdx.y, mbase = blockIdx.z * (MT * 16);
@@ -239,6 +245,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     xload(0);
+    stamp();                                                            // 1: W ring prologue + x chunk 0 issued
     float* const rs = ssq ? (float*)(smem + RS_OFF) : nullptr;
     if (ssq && tid < MT * 16) {                                        // fixed summation order: the scale of a row does not depend on the block that computes it
         const int m = mbase + tid;
@@ -247,12 +254,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
         rs[tid] = rsqrtf((((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) / (float)K + eps);
     }
     xstore(0);
+    stamp();                                                            // 2: x chunk 0 arrived and written to LDS
     __syncthreads();
+    stamp();                                                            // 3: block barrier
 #pragma unroll
     for (int c = 0; c < NCK; ++c) {
         if (c + 1 < NCK) xload(c + 1);
         const char* xt = smem + (XDB ? (c & 1) * XB : 0);
         skinny_mfma_chunk<MT>(xt, lr, g, wr[c % D], acc);
+        if constexpr (PROF) stamp();                                    // 4 + 3c: fragment reads + MFMAs of chunk c issued (W(c) was already in registers: the x wait below retires it, loads return in order)
         if (c + D < NCK) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) wr[c % D][i] = *(const bf16x8*)(wp + (c + D) * WCH + i * WI);
@@ -260,18 +270,21 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
         if (c + 1 < NCK) {
             if (!XDB) __syncthreads();
             xstore(XDB ? ((c + 1) & 1) : 0);
+            if constexpr (PROF) stamp();                                // 5 + 3c: x(c+1) -- and with it every older load: W(c+1) -- landed, tile written
             __syncthreads();
-        }
+        } else if constexpr (PROF) stamp();
+        if constexpr (PROF) stamp();                                    // 6 + 3c: block barrier
     }
     if constexpr (EPI == 1) skinny_store_swiglu<MT, NW>(smem, acc, (bf16*)out, M, N / 2, mbase, bx, w, g, lr, tid, rs);
     else skinny_store_tile<MT, NW>(smem, acc, out + (long)split * M * N, M, N, mbase, bx * BN, w, g, lr, tid, wt, rs);
+    if constexpr (PROF) { stamp(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); }      // epilogue issued / stores acknowledged
 }
 // Deferred-1/rms RMSNorm site handed down the decode GEMM dispatch (round 6): ssq [M][8] partial sums of squares + eps; null = off.
 struct SkRowScale { const float* ssq = nullptr; float eps = 0.f; };
-template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false>
+template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false, bool PROF = false>
 static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, SkRowScale rsc = {}) {
     constexpr int LDS = sk3_main_lds(MT, NW, XDB) + MT * 16 * 4;      // + the row scales (used only with rsc.ssq)
-    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED>;
+    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED, PROF>;
     (void)PG_DYN_LDS(kfn, LDS);
     dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, rsc.ssq, M, N, K, pg_tune->wt_store & 1, rsc.eps);
@@ -551,6 +564,7 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
     unsigned long long* pw = (PROF && prof) ? prof + ((long)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (4 * MS) + (threadIdx.x >> 6)) * 64 : nullptr;
     auto stamp = [&]() { if constexpr (PROF) { if (pw && (threadIdx.x & 63) == 0 && pslot < 64) pw[pslot] = __builtin_readcyclecounter(); ++pslot; } };
     stamp();
+    if constexpr (ABL & 8192) return;                                // ABL 8192 (bench only): an EMPTY kernel of the same geometry -- what the launch itself costs
     constexpr int XB = MT * 16 * 256;                                // bytes per x chunk slot
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, lr = l & 15;
     const int wn = w & 3, wm = w >> 2;
@@ -638,6 +652,195 @@ __global__ __launch_bounds__(256 * MS, OCC) void gemm_sk4_kernel(const bf16* __r
     else { static_assert(EPI != 0 || MS == 1, "transposed epilogues: MS = 1"); skinny_store_tile<MT, 4>(smem, acc, out + (long)split * M * N, M, N, mbase, blockIdx.x * 64, w, g, lr, tid); }
     if constexpr (PROF) { if (pw) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); } }
 }
+// ------------------------------------------------------------------------------- skinny GEMM v5 (round 6): the wide-N GEMMs at 65..128 rows
+// Why: at 128 rows qkv and gate|up ran on the v3 8-wave blocks (64 rows x 128 columns, x tile through registers).  Three things held them at
+// 2.4-2.7 TB/s (profiles/r06_*): (1) every wave reads the block's whole x chunk from LDS for ONE 16-column n-tile -- 1 KiB of fragment reads per MFMA,
+// twice what the LDS delivers while the MFMAs run (gate|up: 6.8 us of LDS reads for 3.9 us of MFMAs); (2) the x tile's staging registers are waited for
+// with the W ring on the same in-order vmcnt counter: the wait for x(c+1) also retires every older W load, so the ring never holds more than ONE
+// chunk in flight (32 KiB of W per CU = one memory round trip per chunk, whatever its depth); (3) x costs a VGPR round trip and an LDS write.
+// v5: the same 64-row x 128-column block and grid (so the second row block's weights still come from L2), 8 waves = 4 n-tile PAIRS x 2 K halves:
+//   * a wave owns 32 columns and HALF of the block's K range: one x fragment feeds two MFMAs (half the LDS reads per MFMA) and the two K halves
+//     stream two independent parts of the weight matrix (twice the requests in flight per column);
+//   * x by LDS-DMA (v4's ring, XOR-swizzled source, no VGPRs), W through an asm-ordered register ring of WD chunks (8 x 1 KiB per chunk per wave),
+//     ONE hand-counted vmcnt per wait (sk5_wait_*: the issue order is simulated at compile time, tools/sk5_isa_check.py replays the compiled code):
+//     the x wait no longer drains the ring -- WD x 8 KiB of W per wave stay in flight (192 KiB per CU at WD = 3);
+//   * x chunk c+1 is retired at chunk c's barrier and read one barrier later (the staging rule of tools/dma_isa_check.py, strict form);
+//   * the two K halves meet once, through LDS, after the loop: every wave hands the n-tile it does not finalise to its partner and finalises the
+//     other one (sum = half 0 + half 1, fixed order), then the v4 direct epilogues (16-byte write-through slab stores / SwiGLU).
+constexpr int sk5_wait_x(int c, int NH, int XD, int WD, int pre = 0) {     // ops that may stay outstanding so that X(min(c + 1, NH - 1)) has landed; pre: the prologue's wait for X(0)
+    int ops = 0, lastX[64] = {};
+    for (int p = 0; p < XD - 1 && p < NH; ++p) { ops += 4; lastX[p] = ops; }
+    for (int p = 0; p < WD && p < NH; ++p) ops += 8;
+    if (pre) return ops - lastX[0];
+    for (int it = 0; it < NH; ++it) {
+        if (it == c) return ops - lastX[(c + 1 < NH) ? c + 1 : NH - 1];
+        if (it + XD - 1 < NH) { ops += 4; lastX[it + XD - 1] = ops; }
+        if (it + WD < NH) ops += 8;
+    }
+    return 0;
+}
+constexpr int sk5_wait_w(int c, int NH, int XD, int WD) {                 // ops that may stay outstanding so that W(c) has landed, evaluated behind the issue of X(c + XD - 1)
+    int ops = 0, lastW[64] = {};
+    for (int p = 0; p < XD - 1 && p < NH; ++p) ops += 4;
+    for (int p = 0; p < WD && p < NH; ++p) { ops += 8; lastW[p] = ops; }
+    for (int it = 0; it < NH; ++it) {
+        if (it + XD - 1 < NH) ops += 4;
+        if (it == c) return ops - lastW[c];
+        if (it + WD < NH) { ops += 8; lastW[it + WD] = ops; }
+    }
+    return 0;
+}
+template <int N_> __device__ __forceinline__ void wait_vmcnt_w2(bf16x8 (&wv)[2][4]) {
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(wv[0][0]), "+v"(wv[0][1]), "+v"(wv[0][2]), "+v"(wv[0][3]), "+v"(wv[1][0]), "+v"(wv[1][1]), "+v"(wv[1][2]), "+v"(wv[1][3])
+                 : "n"(N_ > 63 ? 63 : N_) : "memory");
+}
+template <int C, int NH, class F> __device__ __forceinline__ void sk5_static_for(F&& f) {
+    if constexpr (C < NH) { f(std::integral_constant<int, C>{}); sk5_static_for<C + 1, NH>(f); }
+}
+// EPI 4: fp32 split-K slab, write-through stores; EPI 3: SwiGLU -> bf16 h [M][N/2].  NCK = chunks of the block's K range (even).
+template <int NCK, int XD, int WD, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_sk5_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W, float* __restrict__ out,
+                                                       const float* __restrict__ ssq, int M, int N, int K, float eps) {
+    static_assert(NCK % 2 == 0 && XD >= 3 && WD >= 1, "two K halves; the x ring holds the chunk being read, the retired next one and one in flight");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NH = NCK / 2;                                       // chunks per K half
+    constexpr int XH = 64 * 256, XS = 2 * XH;                         // bytes per (half, chunk) x tile / per ring slot (both halves)
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, lr = l & 15;
+    const int pr = w & 3, h = w >> 2;                                 // n-tile pair of the block, K half
+    const int split = blockIdx.y, mbase = blockIdx.z * 64;
+    const int nt0 = blockIdx.x * 8 + pr * 2, ntiles = N >> 4;
+    const int kc0 = split * NCK + h * NH;                             // first 128-wide K chunk of this wave's half
+    const bf16* wp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) wp[q] = W + ((long)(nt0 + q < ntiles ? nt0 + q : ntiles - 1) * (K / SK_BK) + kc0) * 2048 + l * 8;
+    // x DMA: the 4 waves of half h stage that half's 16 pieces (4 rows each) of every chunk; wave (pr, h) owns pieces 4 pr .. 4 pr + 3
+    const bf16* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (pr * 4 + j) * 4 + (l >> 4), m = mbase + r;
+        xsrc[j] = x + (long)(m < M ? m : M - 1) * K + (long)kc0 * SK_BK + (((l & 15) ^ (r & 15)) << 3);
+    }
+    auto issueX = [&](int c) __attribute__((always_inline)) {
+        char* slot = smem + (c % XD) * XS + h * XH + pr * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(xsrc[j] + c * SK_BK, slot + j * 1024);
+    };
+    // deferred-1/rms RMSNorm (kernels.h): lane (lr, g) fetches the 8 partial sums of squares of row mbase + 16 g + lr -- the OLDEST VMEM operations of
+    // the wave, so every counted wait below (they all retire something younger) has them landed and the counts need not know them; the scale is
+    // formed in the epilogue and handed to the lanes that finalise the row by shuffles.  ssq == nullptr: x is already normalised.
+    f32x4 sqa = {0.f, 0.f, 0.f, 0.f}, sqb = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int m = mbase + g * 16 + lr;
+        const float* pp = (ssq ? ssq : (const float*)x) + (ssq ? (long)(m < M ? m : M - 1) * 8 : 0);      // branch-free: without ssq a harmless read of x[0..7]
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(sqa), "=&v"(sqb) : "v"(pp) : "memory");
+    }
+    bf16x8 wr[WD][2][4];
+    f32x4 acc[2][4];                                                  // [n-tile of the pair][m-tile]
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < XD - 1 && c < NH; ++c) issueX(c);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < WD && c < NH; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sk4_wload(wr[c][q][i], wp[q] + c * 2048 + i * 512);
+    // X(0) retired one barrier before its first read (strict staging rule)
+    wait_vmcnt<sk5_wait_x(0, NH, XD, WD, 1)>();
+    __builtin_amdgcn_s_barrier();
+    sk5_static_for<0, NH>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        wait_vmcnt<sk5_wait_x(c, NH, XD, WD)>();                     // this wave's pieces of X(c + 1) have landed
+        __builtin_amdgcn_s_barrier();                                 // ... every wave's have; every wave is done reading X(c - 1)
+        if constexpr (c + XD - 1 < NH) issueX(c + XD - 1);            // into the slot of X(c - 1)
+        wait_vmcnt_w2<sk5_wait_w(c, NH, XD, WD)>(wr[c % WD]);         // W(c) landed (younger loads stay in flight)
+        {
+            const char* rp = smem + (c % XD) * XS + h * XH + lr * 256;
+            int so[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) so[i] = ((i * 4 + g) ^ lr) << 4;
+            bf16x8 af[2][2][4];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[0][hh][i] = *(const bf16x8*)(rp + hh * 4096 + so[i]);
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                if (p2 == 0) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[1][hh][i] = *(const bf16x8*)(rp + (2 + hh) * 4096 + so[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        acc[q][2 * p2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[c % WD][q][i], af[p2][0][i], acc[q][2 * p2], 0, 0, 0);
+                        acc[q][2 * p2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[c % WD][q][i], af[p2][1][i], acc[q][2 * p2 + 1], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (c + WD < NH) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sk4_wload(wr[c % WD][q][i], wp[q] + (c + WD) * 2048 + i * 512);
+        }
+    });
+    // the two K halves meet: wave (pr, h) hands the partial sums of n-tile 1 - h to its partner (pr, 1 - h) and finalises n-tile h
+    __syncthreads();                                                  // every wave is past its last x fragment read: the ring becomes the exchange buffer
+    f32x4* xch = (f32x4*)smem;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xch[((w * 4 + mt) << 6) + l] = acc[1 - h][mt];
+    __syncthreads();
+    // the loads of sqa / sqb are older than everything the loop waited for: landed (asm outputs: the compiler must not use them before this point's
+    // explicit wait -- nothing is outstanding any more except the last W chunks' loads, all consumed)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sqa), "+v"(sqb)::"memory");
+    const float myrs = ssq ? rsqrtf((((sqa.x + sqa.y) + (sqa.z + sqa.w)) + ((sqb.x + sqb.y) + (sqb.z + sqb.w))) / (float)K + eps) : 1.f;
+    float rsc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) rsc[mt] = __shfl(myrs, mt * 16 + lr, 64);
+    f32x4 fin[4];
+    const int pw = (w ^ 4);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 o = xch[((pw * 4 + mt) << 6) + l];
+        const f32x4 a0 = h == 0 ? acc[0][mt] : o, a1 = h == 0 ? o : acc[1][mt];     // half 0 + half 1, in that order for both n-tiles
+        fin[mt] = a0 + a1;
+        fin[mt] *= rsc[mt];
+    }
+    const int ntile = nt0 + h;
+    if (ntile < ntiles) {
+        if constexpr (EPI == 3) sk4_store_swiglu_direct<4>(fin, (bf16*)out, M, N / 2, mbase, ntile, g, lr);
+        else sk4_store_direct<4, true>(fin, out + (long)split * M * N, M, N, mbase, ntile * 16, g, lr);
+    }
+}
+template <int NCK, int EPI>
+static void launch_sk5(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S, SkRowScale rsc) {
+    constexpr int XD = 4, WD = 3;
+    constexpr int LDS = XD * 2 * 64 * 256;                            // 128 KiB: the x ring (the 32 KiB exchange buffer aliases it)
+    auto kfn = gemm_sk5_kernel<NCK, XD, WD, EPI>;
+    (void)PG_DYN_LDS(kfn, LDS);
+    dim3 grid(N / 128, S, (M + 63) / 64), block(512);
+    hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, Wt, out, rsc.ssq, M, N, K, rsc.eps);
+}
+// true when the shape has a v5 instantiation: N a multiple of 128, K range of the block 8 or 16 chunks
+template <int EPI>
+static bool sk5_try(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S, SkRowScale rsc = {}) {
+    if (!Wt || (N % 128) || M > 128 || S < 1 || K % (SK_BK * S)) return false;
+    const int nck = K / SK_BK / S;
+    if (nck == 16) { launch_sk5<16, EPI>(s, x, Wt, out, M, N, K, S, rsc); return true; }
+    if (nck == 8) { launch_sk5<8, EPI>(s, x, Wt, out, M, N, K, S, rsc); return true; }
+    return false;
+}
+
 extern unsigned long long* g_sk4_prof;          // stamp buffer of the PROF instantiations (libplangen_diag.so: tools/sk4_profile.py); null in production
 template <int MT, int NCK, int XD, int WD, int EPI, int OCC, int ABL = 0, int MS = 1>
 static void launch_sk4(hipStream_t s, const bf16* x, const bf16* Wt, float* out, int M, int N, int K, int S, const void* tail = nullptr) {      // tail: EPI 5's SkFuse site

@@ -25,7 +25,8 @@ K_CROSS = 1.25          # p99 |hip_bf16 - ref_bf16| over p99 E_ref.  Two differe
                         # <= 1.0 is only reachable when E_hip << E_ref; measured on MI355X (round 6) 1.04-1.10 on the image loop at E_hip = 0.55-0.74 E_ref and
                         # 1.16-1.18 on the text path at E_hip = E_ref (independent roundings would give 1.17-1.25 and 1.41: the shared bf16 weight rounding correlates
                         # them).  Reported in every test's printed ratios and in DESIGN.md section 2 as a finding; bounded at the verdict's cap.
-AGREE_SLACK = 0.02      # teacher-forced argmax agreement may sit this far below the reference-bf16's (bf16 logits tie often; <= 1152 samples)
+AGREE_SLACK = 0.02      # teacher-forced argmax agreement may sit this far below the reference-bf16's (bf16 logits tie often) -- or two samples' worth on
+                        # the small fixtures (24 layers x 2 images x 16 steps = 32 samples: one flipped step is 0.031), see agree_slack()
 STATS = ("max", "p999", "p99", "p50", "mean")
 
 
@@ -46,6 +47,10 @@ def pct(x, q):
 def err_stats(d):
     d = d.float().numpy().reshape(-1)
     return {"max": float(d.max()), "p999": pct(d, 99.9), "p99": pct(d, 99), "p50": pct(d, 50), "mean": float(d.mean())}
+
+
+def agree_slack(n_samples):
+    return max(AGREE_SLACK, 2.0 / max(int(n_samples), 1))
 
 
 def limit(stat_name):
@@ -109,7 +114,7 @@ def check_image_loop(name, logits, toks, g32, what, images=None, steps=None):
     print(f"{what}: reference-relative bf16:", json.dumps(rep))
     bad = over_limit(ratios)
     assert not bad, f"E_hip exceeds K x E_ref (K = {K} on quantiles, {K_MAX} on maxima, {K_CROSS} on the distance to the reference's bf16; a finding, not a tolerance to widen): {bad}"
-    assert H["teacher_forced_agreement"] >= E["teacher_forced_agreement"] - AGREE_SLACK, (H["teacher_forced_agreement"], E["teacher_forced_agreement"])
+    assert H["teacher_forced_agreement"] >= E["teacher_forced_agreement"] - agree_slack(agree.numel()), (H["teacher_forced_agreement"], E["teacher_forced_agreement"], agree.numel())
     # a flipped argmax is only legitimate inside twice the engine's OWN worst error (consistency of the two measurements, not a tolerance)
     err_bound = max(H["all"]["max"], H["top1_value_err_max_all_steps"])
     assert not ((~agree) & (margin > 2 * err_bound)).any(), rep

@@ -1,6 +1,7 @@
 """CPU: the LDS-DMA staging protocols of every global_load_lds kernel, checked against the code hipcc actually emits for gfx950.
 
-tools/dma_isa_check.py replays each kernel's instruction stream (VMEM operations retire in issue order): the prefill flash
+tools/dma_isa_check.py replays each kernel's instruction stream (VMEM operations retire in issue order; round 6: the two-phase 256x256 GEMM's
+WAR margin with its wave groups one barrier apart, and the v5 decode GEMM's whole hand-counted stream, tools/sk5_isa_check.py): the prefill flash
 attention, the 256x256 GEMM and the halo convolution's weight ring must retire a staged tile ONE BARRIER BEFORE the phase that
 reads it and re-stage a slot only behind a barrier that follows its last read; tools/sk4_isa_check.py (called from it) walks the
 114 decode-GEMM instantiations with their hand-counted `s_waitcnt vmcnt(N)`.  A compiler that reorders a load across a counted
@@ -33,6 +34,7 @@ def test_lds_dma_protocols_match_the_compiled_code():
     assert v.get("fifo_weak", 0) <= 1        # only the diagnostics library's big-wave GEMM experiment (diag_gemm_bw.hip) reads behind its retiring barrier
     assert set(v) <= {"fifo", "fifo_weak", "halo_stag", "big", "halo_lock", "once", "sink"}  # every PRODUCT kernel is on a STRICT spec (no same-phase form left)
     assert r["sk4"]["rc"] == 0 and r["sk4"]["failed"] == 0 and r["sk4"]["checked"] >= 40   # production + bench instantiations of the decode GEMM
+    assert r["sk5"]["failed"] == 0 and r["sk5"]["checked"] >= 4                             # round 6: the v5 wide-N kernel (8 / 16 chunks x slab / SwiGLU epilogue), exact stream replay
 
 
 def test_inline_asm_stores_carry_their_wait_states():

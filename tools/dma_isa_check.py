@@ -232,6 +232,8 @@ SPECS = [
                                         why="four-phase form: half-tiles retired by vmcnt(8) in the phase before they are read; a slot is re-staged >= 2 phases after its last read")),
     ("diag_gemm_bw", r"gemm_bw_kernel", dict(kind="fifo", g=8, need="bw", tile_cls=lambda n: 0, slot_reuse=lambda c: 4, strict=False,
                                             why="libplangen_diag.so experiment: 4-stage ring, tile t+1 retired by vmcnt(8) + the barrier of iteration t and first read behind that barrier (weak form)")),
+    ("gemm", r"gemm_sk5_kernel", dict(kind="sk5")),
+    ("diag_gemm", r"gemm_sk5_kernel", dict(kind="sk5")),
     ("gemm", r"gemm_sk4_kernel", dict(kind="sk4")),
     ("diag_gemm", r"gemm_sk4_kernel", dict(kind="sk4")),
     ("bench_kernels", r"gemm_sk4_kernel", dict(kind="sk4")),
@@ -285,7 +287,7 @@ def main():
                 else:
                     okc[spec["kind"] if sp.get("strict", True) else "fifo_weak"] += 1
                     report.append(f"ok   {fname}:{short}: fifo protocol holds in the {'strict' if sp.get('strict', True) else 'weak'} form over 6 replayed iterations ({n} DMA instructions)")
-            elif spec["kind"] == "sk4":
+            elif spec["kind"] in ("sk4", "sk5"):
                 continue
             elif spec["kind"] == "halo_stag":
                 # steady state of the tap loop (two K tiles per iteration): [16 fragment reads, stage W(t+2), vmcnt(2), barrier, MFMAs, barrier];
@@ -372,10 +374,22 @@ def main():
             sk4_checked += int(m.group(1)); sk4_failed += int(m.group(2))
         else:
             sk4_checked = -1
+    # v5 decode GEMM (round 6): exact replay of its hand-counted stream (tools/sk5_isa_check.py), production + diagnostics instantiations
+    sk5_checked = sk5_failed = 0
+    for unit in ("gemm", "diag_gemm"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sk5_isa_check.py"), _S_PATH[unit]], capture_output=True, text=True)
+        last = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "no output"
+        report.append(f"sk5 ({unit}.hip): " + last)
+        m = re.match(r"(\d+) instantiations checked, (\d+) failed", last)
+        if m:
+            sk5_checked += int(m.group(1)); sk5_failed += int(m.group(2))
+        if p.returncode != 0 and unit == "gemm" or (m and int(m.group(2))):
+            bad += 1
+            report += [l for l in p.stdout.strip().splitlines() if l.startswith("FAIL")][:5]
     print("\n".join(report))
     # one machine-readable line for tests/test_isa_check.py (wording of the lines above is free to change)
     print("SUMMARY " + json.dumps({"failed": bad, "verified": dict(okc), "notes": sum(1 for l in report if l.startswith("note")),
-                                   "sk4": {"checked": sk4_checked, "failed": sk4_failed, "rc": sk4_rc},
+                                   "sk4": {"checked": sk4_checked, "failed": sk4_failed, "rc": sk4_rc}, "sk5": {"checked": sk5_checked, "failed": sk5_failed},
                                    "compiler": _compiler_id()[:80]}))
     print(f"{bad} failed")
     return 1 if bad else 0
