@@ -378,10 +378,9 @@ __global__ __launch_bounds__(512) void conv3x3_out_gn_kernel(const float* __rest
     const int c4 = tid & 31;
     f32x4 xv[CO_NV];
     unsigned okmask = 0;
-    // address + in-image flag of vector ``it`` of tile ``tix`` (clamped: the load is unconditional, the value masked)
-    auto src_of = [&](int tix, int it, bool& ok) __attribute__((always_inline)) -> const f32x4* {
-        const int b = tix / tiles_img, r = tix - b * tiles_img;
-        const int y0 = (r / tiles_x) * CO_TH, x0 = (r % tiles_x) * CH_TW;
+    // address + in-image flag of vector ``it`` of the tile at (image base, y0, x0) (clamped: the load is unconditional, the value masked).  The tile ->
+    // (image, y0, x0) divisions are done ONCE per tile by the caller: inside this per-vector helper they cost more than the normalisation itself.
+    auto src_of = [&](const float* img, int y0, int x0, int it, bool& ok) __attribute__((always_inline)) -> const f32x4* {
         int hp = it * 16 + (tid >> 5);
         const bool inr = hp < CO_HP;
         hp = inr ? hp : CO_HP - 1;
@@ -389,21 +388,27 @@ __global__ __launch_bounds__(512) void conv3x3_out_gn_kernel(const float* __rest
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         ok = inr && y >= 0 && y < H && x >= 0 && x < Wd;
         const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= Wd ? Wd - 1 : x);
-        return (const f32x4*)(X + (long)b * H * Wd * 128 + ((long)yc * Wd + xc) * 128 + c4 * 4);
+        return (const f32x4*)(img + ((long)yc * Wd + xc) * 128 + c4 * 4);
+    };
+    auto tile_of = [&](int tix, const float*& img, int& b, int& y0, int& x0) __attribute__((always_inline)) {
+        b = tix / tiles_img;
+        const int r = tix - b * tiles_img, ty = r / tiles_x;
+        y0 = ty * CO_TH; x0 = (r - ty * tiles_x) * CH_TW;
+        img = X + (long)b * H * Wd * 128;
     };
     const int orow = w >> 1, omt = w & 1;                         // wave w: output row w >> 1 of the 4 x 32 tile, pixels (w & 1) * 16 .. +15
     const int hp0 = orow * CH_HW + omt * 16 + lr;
     int tix = blockIdx.x;
+    const float* img_n = X; int b_n = 0, y0_n = 0, x0_n = 0;
     if (tix < NT) {
+        tile_of(tix, img_n, b_n, y0_n, x0_n);
 #pragma unroll
-        for (int it = 0; it < CO_NV; ++it) { bool ok; xv[it] = *src_of(tix, it, ok); okmask |= ok ? (1u << it) : 0u; }
+        for (int it = 0; it < CO_NV; ++it) { bool ok; xv[it] = *src_of(img_n, y0_n, x0_n, it, ok); okmask |= ok ? (1u << it) : 0u; }
     }
     for (; tix < NT; tix += G) {
-        const int b = tix / tiles_img, r = tix - b * tiles_img;
-        const int y0 = (r / tiles_x) * CO_TH, x0 = (r % tiles_x) * CH_TW;
+        const int b = b_n, y0 = y0_n, x0 = x0_n;                    // this tile (computed when its loads were issued)
         const f32x4 ca = *(const f32x4*)(coef + ((long)b * 128 + c4 * 4) * 2), cb = *(const f32x4*)(coef + ((long)b * 128 + c4 * 4) * 2 + 4);   // a0 sh0 a1 sh1 | a2 sh2 a3 sh3
-        const bool more = tix + G < NT;
-        const int tnext = more ? tix + G : tix;
+        if (tix + G < NT) tile_of(tix + G, img_n, b_n, y0_n, x0_n);   // the next tile (the last one re-reads itself and drops the data)
         unsigned oknext = 0;
         // vector by vector: normalise + swish + pack, then the SAME register is re-armed with the next tile's vector (its load flies under the rest of
         // this loop, the MFMA phase and the stores), then the packed value goes to LDS.  In-order returns: the next tile consumes xv[0] first.
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(512) void conv3x3_out_gn_kernel(const float* __rest
             const int hp = it * 16 + (tid >> 5);
             float t0 = fmaf(xv[it][0], ca[0], ca[1]), t1 = fmaf(xv[it][1], ca[2], ca[3]), t2 = fmaf(xv[it][2], cb[0], cb[1]), t3 = fmaf(xv[it][3], cb[2], cb[3]);
             bool okn;
-            const f32x4* nsrc = src_of(tnext, it, okn);
+            const f32x4* nsrc = src_of(img_n, y0_n, x0_n, it, okn);
             xv[it] = *nsrc; oknext |= okn ? (1u << it) : 0u;      // unconditional (the last tile re-reads itself and drops it): a conditional load costs a vmcnt(0) at the join
             if (swish) {                                          // gn_apply_kernel's bf16-output form
                 t0 = t0 * __frcp_rn(1.f + __expf(-t0)); t1 = t1 * __frcp_rn(1.f + __expf(-t1));

@@ -26,8 +26,9 @@ struct PgTune {
     int vit_attn = 2;                                           // SigLIP attention: 2 = K / V^T of a head resident in LDS (round 4), 1 = 64-key tile kernel
     int ln_wave = 1;                                            // SigLIP LayerNorm: wave-per-row register kernel (0: generic block-per-row kernel)
     int wt_store = 0;                                           // v3 decode GEMM slabs with write-through (sc1) stores (libplangen_diag.so only)
-    int sk5 = 1;                                                // decode GEMMs at 65..128 rows, wide N: the v5 kernel (n-tile pairs x two K halves, x by LDS-DMA; gemm_skinny.h).  0 (libplangen_diag.so only:
-                                                                // the bf16 sums round differently) = the round-5 v3 blocks
+    int sk5 = 0;                                                // 1 (libplangen_diag.so only: the bf16 sums round differently): the v5 kernel for the wide-N decode GEMMs at 65..128 rows (n-tile pairs x
+                                                                // two K halves, x by LDS-DMA; gemm_skinny.h).  Measured in round 6: on par in the microbenchmark, +80 ms per bs=64 step in the loop
+                                                                // (profiles/r06_b) -- NOT the default; kept selectable for A/B
     int stream_gemm = -1;                                       // -1 auto, else bit mask: which decode GEMM classes run on the v4 LDS-DMA kernel (gemm.hip sk4_prod)
     const struct PgDiagHooks* diag = nullptr;                   // null in libplangen_hip.so; libplangen_diag.so (diag_api.hip) points it at its variant launchers
 };

@@ -20,7 +20,10 @@ def csrc_sha():
 
 def classify(name):
     if "attn_decode_fused_kernel" in name: return "decode_attention"
-    if "rmsnorm512_kernel" in name or "rmsnorm_kernel" in name: return "decode_rmsnorm"
+    if "rmsnorm512_kernel" in name or "rmsnorm_kernel" in name or "rmsnorm_defer_kernel" in name: return "decode_rmsnorm"      # round 6: the deferred-1/rms form at 65..128 rows
+    if "gemm_sk5_kernel" in name:
+        m = re.search(r"gemm_sk5_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+        if m: return "decode_gemm_gate_up_swiglu" if int(m.group(4)) == 3 else {8: "decode_gemm_qkv", 16: "decode_gen_head_w2"}.get(int(m.group(1)))
     m = re.search(r"gemm_sk4_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
     if m:
         nck, epi = int(m.group(2)), int(m.group(5))
