@@ -220,8 +220,8 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *     conv_halo (1)          direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: implicit-GEMM kernel)
  *     vq_mid_bf16 (1)        bf16 mode: the tensor between a ResnetBlock's two convolutions is bf16 (statistics from the fp32
  *                            accumulators); 0 keeps it fp32 like the skip stream
- *     vq_tail_fused (1)      decoder tail conv_out(swish(norm_out(h))) (vq_model.py:210-214) in one pass over the fp32 skip stream; 0 = GroupNorm apply
- *                            pass + conv_out.  Bit-identical pixels.
+ *     vq_tail_fused (0)      1 = decoder tail conv_out(swish(norm_out(h))) (vq_model.py:210-214) in one pass over the fp32 skip stream instead of a GroupNorm
+ *                            apply pass + conv_out.  Bit-identical pixels; measured slower in round 6 (4.05 vs 3.4 ms at 64 images), hence off.
  *     vq_argmin_multi (1)    nearest-code search: 8 latent vectors per block (0: one per block); identical indices
  *   SigLIP
  *     vit_attn (2)           2 = K / V^T of a head resident in LDS, 16 waves per block; 4 / 8 / 12 / 16 = that kernel with so many waves;

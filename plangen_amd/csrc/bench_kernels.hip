@@ -314,7 +314,7 @@ extern "C" int pg_bench_conv_gn_check(int B, int Hi, int Wi, int Cin, int Cout, 
     int ns = 0;
     ga.gn_part = wsB; ga.gn_nsplit = &ns; ga.gn_hw = plain ? (int)HW : 0;
     GemmEpi e; e.out = o0; e.out_f32 = 1; e.ldc = Cout; e.bias_n = gam; e.residual = rsd; e.res_f32 = 1;
-    PgTune tune; tune.diag = diag_hooks(); tune.gemm256 = gemm256_mode; const PgTune* const saved = pg_tune; pg_tune = &tune;
+    PgTune tune; tune.diag = diag_hooks(); tune.gemm256 = gemm256_mode; tune.gn_epilogue256 = 1; const PgTune* const saved = pg_tune; pg_tune = &tune;
     hipMemsetAsync(wsB, 0xff, (size_t)B * 1024 * 64 * 4, s);                     // NaN pattern: a slot nobody writes shows up
     launch_gemm<bf16>(s, ga, Wt, K, 0, e, (int)M, Cout, K, 1);
     pg_tune = saved;

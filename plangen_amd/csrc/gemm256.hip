@@ -57,7 +57,8 @@ __device__ __forceinline__ void g2_barrier() { asm volatile("s_barrier" ::: "mem
 // 424 tiles of 256 rows = 1.66 rounds on 256 CUs (17 % of the launch idle) but 480 tiles of 224 rows = 1.875 rounds of 7/8 the work.  Only
 // the fragment reads and MFMAs of the second half shrink (phases 3 / 4: 4 x MT1 MFMAs... MT1 m-tiles x 2 n-tiles x 2 k-steps); the staging
 // stream, its counted waits and the LDS layout are unchanged (the half-tile HA1 still brings 64 rows per wave row, 64 - 16 MT1 of them unused).
-template <class AL, class EP, int WM, int WN, bool ROPE = false, int MT1 = 4, int PH = 4>      // ROPE: the prefill QKV instantiation (RoPE + KV-write epilogue, act 3) -- its own kernel so its
+template <class AL, class EP, int WM, int WN, bool ROPE = false, int MT1 = 4, int PH = 4, bool GN = false>      // GN (round 6): the epilogue also emits GroupNorm partial sums -- its own instantiation: in the common one its
+                                                                                                              // extra live registers spilled 27-61 VGPRs and cost the prefill GEMMs 1.5 %.  ROPE: the prefill QKV instantiation (RoPE + KV-write epilogue, act 3) -- its own kernel so its
 __global__ __launch_bounds__(512) void gemm256_kernel(                 // register needs do not reach the other users of this template
 AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                                                      long strideA2, long strideB2, EP ep, int M, int N, int K, int ntm, int ntn) {
@@ -375,28 +376,32 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                         *(uint2*)(hout + (long)row * ep.e.ldc + col) = q;
                     }
                 }
-        } else if (NMT == 8 && ep.e.gn_part && vec) {
+        } else if (GN && NMT == 8 && vec) {
             // GroupNorm(32) statistics of the values being stored (round 6; conv_halo.hip does the same for the 384^2 / 192^2 levels): a wave owns two
             // 64-row chunks x 64 columns; a chunk never straddles an image (HW % 64 == 0, checked by gemm256_try), so every (image, chunk, group)
             // slot has exactly ONE writer -- fixed-order reduction (4 m-tiles in registers, 16 row lanes + the group's column lanes by shuffles), no
             // atomics; gn_finalize_kernel adds an image's chunks in double.  Replaces the separate gn_stats pass over the stored tensor.
             const int cpg = ep.e.gn_cpg, hw = ep.e.gn_hw, nsplit = hw >> 6;
+            // image / chunk of the tile's first row: ONE wave-uniform division per tile (hw >= 256: a 256-row tile crosses at most one image boundary)
+            const int tm0 = __builtin_amdgcn_readfirstlane(em0 - lr) - wr * WROWS;
+            const int tb0 = tm0 / hw, trem = tm0 - tb0 * hw;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int mq = 0; mq < 2; ++mq) {
-                    const int mp = h * 2 + mq;
-                    int rows[8], cols[8]; f32x4 av[8], vo[8];
+                for (int mq = 0; mq < 4; ++mq) {                          // one m-tile row (4 fragments) per batch, stored values returned IN PLACE: no second fragment array
+                    const int mt = h * 4 + mq;
+                    int rows[4], cols[4]; f32x4 av[4];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { rows[i] = em0 + (mp * 2 + (i >> 2)) * 16; cols[i] = en0 + (i & 3) * 16; av[i] = acc[mp * 2 + (i >> 2)][i & 3]; }
-                    ep.template store4_batch<8>(coff, roff, rows, cols, av, true, vo);
+                    for (int i = 0; i < 4; ++i) { rows[i] = em0 + mt * 16; cols[i] = en0 + i * 16; av[i] = acc[mt][i]; }
+                    ep.template store4_batch<4>(coff, roff, rows, cols, av, true, av);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f32x4 v = vo[i];
-                        s1[i & 3] += (v[0] + v[1]) + (v[2] + v[3]);
-                        s2[i & 3] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 v = av[i];
+                        s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+                        s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);                    // one batch at a time: hoisting the later batches' bias / residual loads up here is what spilled
                 }
                 const int row0 = em0 - lr + h * 64;                    // first row of the chunk
 #pragma unroll
@@ -408,7 +413,9 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
                     const int col = en0 + nt * 16;
                     const bool writer = lr == 0 && (cpg == 4 || (cpg == 8 && (g & 1) == 0) || (cpg == 16 && g == 0));
                     if (writer && row0 < M && col < N) {
-                        const int b = row0 / hw, split = (row0 - b * hw) >> 6;
+                        int off = trem + wr * WROWS + h * 64, b = tb0;
+                        if (off >= hw) { off -= hw; ++b; }
+                        const int split = off >> 6;
                         float* o = ep.e.gn_part + (((long)b * nsplit + split) * 32 + col / cpg) * 2;
                         o[0] = s1[nt]; o[1] = s2[nt];
                     }
@@ -438,7 +445,7 @@ AL al, const bf16* __restrict__ W, long ldb, long strideA, long strideB,
 }
 
 
-template <class AL, int WM, int WN, bool ROPE = false, int MT1 = 4, int PH = 4>
+template <class AL, int WM, int WN, bool ROPE = false, int MT1 = 4, int PH = 4, bool GN = false>
 static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long strideA, long strideB, long strideA2, long strideB2,
                       const Epi<bf16>& ep, int M, int N, int K, int batch, int batch2) {
     constexpr int BM = WM * (64 + 16 * MT1), BN = WN * 64, LDS = 2 * (2 * WM * 64 * 128 + 2 * WN * 32 * 128);
@@ -446,7 +453,7 @@ static void launch256(hipStream_t s, AL al, const bf16* W, long ldb, long stride
     const int ncu = pg_cu_count();
     const int per_batch = ncu / (batch * batch2) > 8 ? ncu / (batch * batch2) : 8;   // blocks per (batch) slice: one per CU overall
     dim3 grid(ntm * ntn < per_batch ? ntm * ntn : per_batch, batch, batch2), block(512);
-    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN, ROPE, MT1, PH>;
+    auto kfn = gemm256_kernel<AL, Epi<bf16>, WM, WN, ROPE, MT1, PH, GN>;
     (void)PG_DYN_LDS(kfn, LDS);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, al, W, ldb, strideA, strideB, strideA2, strideB2, ep, M, N, K, ntm, ntn);
 }
@@ -487,8 +494,8 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
     // 64-row chunk then never straddles two images), dense [M][N] output, 256-row tiles (the chunk arithmetic assumes them)
     GemmEpi eg = e;
     const long out_hw = a.kind == 0 ? a.gn_hw : (a.kind == 2 ? (long)(a.Hi / 2) * (a.Wi / 2) : (long)(a.Hi << a.up) * (a.Wi << a.up));
-    const bool want_gn = a.gn_part && a.gn_nsplit && batch == 1 && batch2 == 1 && e.act == 0 && (N == 128 || N == 256 || N == 512) && e.ldc == N
-                         && out_hw >= 64 && (out_hw % 64) == 0 && (M % out_hw) == 0 && out_hw / 64 <= 1024 && !e.strideC
+    const bool want_gn = pg_tune->gn_epilogue256 && a.gn_part && a.gn_nsplit && batch == 1 && batch2 == 1 && e.act == 0 && (N == 128 || N == 256 || N == 512) && e.ldc == N
+                         && out_hw >= 256 && (out_hw % 64) == 0 && (M % out_hw) == 0 && out_hw / 64 <= 1024 && !e.strideC
                          && (((e.ldr ? e.ldr : e.ldc) | e.ldc) & 3) == 0;          // the kernel's vec_ok() for coff = roff = 0: the partials come out of the vector epilogue only
     if (want_gn) { eg.gn_part = (float*)a.gn_part; eg.gn_hw = (int)out_hw; eg.gn_cpg = N / 32; *a.gn_nsplit = (int)(out_hw / 64); }
     Epi<bf16> ep{eg, M, N};
@@ -496,6 +503,10 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
         PlainLoaderB<bf16> al; al.A = (const bf16*)a.ptr; al.lda = a.lda; al.M = M;
         const int mt1 = want_gn ? 4 : pick_tile_height(M, N, batch * batch2);
 #define G2_LAUNCH(ROPE_, MT1_, PH_) launch256<PlainLoaderB<bf16>, 2, 4, ROPE_, MT1_, PH_>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2)
+        if (want_gn) {        // 1x1 convolution whose output feeds a GroupNorm (AttnBlock.proj_out): the GN instantiation, 256-row tiles, two phases
+            launch256<PlainLoaderB<bf16>, 2, 4, false, 4, 2, true>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+            return true;
+        }
         // two phases per K tile by default (round 5: +2-3 % on every prefill shape, bit-identical); gemm256 bit 3 (value 8) selects the four-phase schedule for A/B
         const bool four = (pg_tune->gemm256 & 8) != 0;
         if (!four) {
@@ -512,7 +523,8 @@ bool gemm256_try(hipStream_t s, const GemmA& a, const bf16* W, long ldb, long st
     const long in_elems = ((long)M / ((long)Ho * Wo)) * a.Hi * a.Wi * a.Cin;
     if (in_elems >= (1L << 31)) return false;             // the slim loader keeps 32-bit element offsets
     ConvLoaderS<4> al; al.setup(a, M);
-    if (pg_tune->gemm256 & 8) launch256<ConvLoaderS<4>, 2, 4, false, 4, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
+    if (want_gn) launch256<ConvLoaderS<4>, 2, 4, false, 4, 2, true>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);      // GroupNorm partials from the epilogue (two-phase form only)
+    else if (pg_tune->gemm256 & 8) launch256<ConvLoaderS<4>, 2, 4, false, 4, 4>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
     else launch256<ConvLoaderS<4>, 2, 4, false, 4, 2>(s, al, W, ldb, a.strideA, strideB, a.strideA2, strideB2, ep, M, N, K, batch, batch2);
     return true;
 }

@@ -21,7 +21,10 @@ struct PgTune {
     int attn_waves = 0;                                         // 4 / 8 pin the decode-attention block size
     int attn_variant = 0;                                       // libplangen_diag.so only: which fused decode-attention form PgDiagHooks::attn_decode launches (0: production)
     int prefill_attn = 2;                                       // MFMA prefill attention: 2 = 128-query LDS-DMA / transpose-read kernel, 1 = 64-query kernel
-    int vq_tail_fused = 1;                                      // VQ decoder tail: norm_out + swish + conv_out in one pass over the fp32 skip stream (0: gn_apply + conv_out; bit-identical)
+    int gn_epilogue256 = 0;                                     // GroupNorm partial sums from the 256x256 kernel's conv epilogue (round 6; libplangen_diag.so switch).  Correct (GPU test) but its
+                                                                // extra live registers spill 48 VGPRs into the K loop: +3.0 ms of convolutions for -2.7 ms of statistics passes.  Off.
+    int vq_tail_fused = 0;                                      // 1: VQ decoder tail norm_out + swish + conv_out in one pass over the fp32 skip stream (bit-identical to gn_apply + conv_out).  Measured
+                                                                // in round 6: 4.05 ms against 1.44 + 1.95 ms for the two passes (profiles/r06_c) -- off by default, kept for A/B
     int vq_argmin_multi = 1;                                    // VQ nearest-code search: 8 latent vectors per block (0: one per block, rounds 1-3)
     int vit_attn = 2;                                           // SigLIP attention: 2 = K / V^T of a head resident in LDS (round 4), 1 = 64-key tile kernel
     int ln_wave = 1;                                            // SigLIP LayerNorm: wave-per-row register kernel (0: generic block-per-row kernel)

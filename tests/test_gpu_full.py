@@ -88,7 +88,7 @@ def test_vq16_fused_tail_equals_groupnorm_apply_plus_conv_out(out_dtype):
         assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().std()) > 0.05
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     finally:
-        e.set_option("vq_tail_fused", 1)
+        e.set_option("vq_tail_fused", 0)
         e.close()
 
 
