@@ -397,3 +397,71 @@ def test_vq_argmin_multi_vector_kernel_equals_one_vector_kernel():
     e.close()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert len(torch.unique(outs[0])) > 100
+
+
+def test_config3_uni_2stage_full_length_bs32():
+    """BASELINE configs[2] at FULL length under the driver's GPUTEST (the full-length runs existed only in builder-run tools):
+    32 stage-1 prompts of 128 tokens -> 256 forced layout tokens (EOS suppressed, positions = mask cumsum) -> the uni path on 64 CFG rows, L = 256,
+    all 576 image tokens, VQ decode.  No reference exists at this size (24 layers x 32 rows x 832 steps on CPU is hours): size-independent properties --
+    ids / tokens in range, pixels finite, the whole pipeline deterministic across two runs, row 0 of the text decode independent of its batch mates."""
+    from bench import synth_prompts
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    cfg = PlanGenConfig.janus_pro_1b()
+    B, L1, L2, NT, T = 32, 128, 256, 256, cfg.img_tokens
+    e = Engine(cfg, dtype="bf16", max_rows=2 * B, max_prompt=L2, max_new=T, max_images=B, with_lm_head=True)
+    e.init_synthetic(seed=0)
+    try:
+        g = torch.Generator().manual_seed(3)
+        ids1 = torch.randint(10, cfg.vocab - 2048, (B, L1), generator=g).int()
+        ids2, mask2 = synth_prompts(B, L2, cfg.vocab, cfg.pad_id, seed=3)
+        pad2 = Engine.pad_len_from_mask(mask2, L2)
+        runs = []
+        for _ in range(2):
+            e.prefill(ids1, [0] * B, position_mode=1)
+            txt = e.generate_text_greedy(NT, cfg.eos_id, min_new_tokens=NT).cpu()
+            e.prefill(ids2, pad2, position_mode=0)
+            toks = e.decode_image_tokens(T=T, cfg_weight=5.0, temperature=1.0, seed=11)
+            img = e.vq_decode(toks).cpu()
+            runs.append((txt, toks.cpu(), img))
+        txt, toks, img = runs[0]
+        assert txt.shape == (B, NT) and ((txt >= 0) & (txt < cfg.vocab)).all() and not (txt == cfg.eos_id).any()
+        assert toks.shape == (B, T) and ((toks >= 0) & (toks < cfg.img_vocab)).all() and len(torch.unique(toks)) > 500
+        assert img.shape == (B, 3, cfg.img_size, cfg.img_size) and torch.isfinite(img).all()
+        assert torch.equal(runs[1][0], txt) and torch.equal(runs[1][1], toks) and torch.equal(runs[1][2], img)
+        e.prefill(ids1[:1].contiguous(), [0], position_mode=1)
+        assert torch.equal(e.generate_text_greedy(NT, cfg.eos_id, min_new_tokens=NT).cpu()[0], txt[0])
+    finally:
+        e.close()
+
+
+def test_config5_mmu_full_length_bs64():
+    """BASELINE configs[4] at FULL length: 64 images -> SigLIP-L + aligner -> prefill of 576 + 64 embeddings per row (positions = mask cumsum, the
+    640-position flash prefill) -> 256 forced answer tokens at contexts 640-895; the VQ encoder on the same images beside it (`t2i` teacher forcing).
+    Properties: shapes / ranges, determinism across two runs, row 0 alone == row 0 in the batch of 64."""
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    cfg = PlanGenConfig.janus_pro_1b()
+    B, P, Lt, NT = 64, cfg.vit_tokens, 64, 256
+    e = Engine(cfg, dtype="bf16", max_rows=B, max_prompt=P + Lt, max_new=NT, max_images=B, with_lm_head=True, with_vq_encoder=True, with_vision=True,
+               max_vision_images=B)
+    e.init_synthetic(seed=0)
+    try:
+        g = torch.Generator().manual_seed(5)
+        pix = torch.rand(B, 3, cfg.vit_img, cfg.vit_img, generator=g) * 2 - 1
+        txt_emb = e.embed_tokens(torch.randint(10, cfg.vocab - 2048, (B, Lt), generator=g).int())
+        outs = []
+        for _ in range(2):
+            feats = e.vision_encode(pix, dtype=torch.bfloat16)
+            emb = torch.cat([txt_emb[:, :1].to(feats.dtype), feats, txt_emb[:, 1:].to(feats.dtype)], 1).contiguous()
+            e.prefill_embeds(emb, [0] * B, position_mode=1)
+            outs.append(e.generate_text_greedy(NT, cfg.eos_id, min_new_tokens=NT).cpu())
+        out = outs[0]
+        assert out.shape == (B, NT) and ((out >= 0) & (out < cfg.vocab)).all() and not (out == cfg.eos_id).any()
+        assert torch.equal(outs[1], out)
+        e.prefill_embeds(emb[:1].contiguous(), [0], position_mode=1)
+        assert torch.equal(e.generate_text_greedy(NT, cfg.eos_id, min_new_tokens=NT).cpu()[0], out[0])
+        idx = e.vq_encode(pix.to(torch.bfloat16)).cpu()
+        assert idx.numel() == B * cfg.img_tokens and ((idx >= 0) & (idx < cfg.img_vocab)).all()
+    finally:
+        e.close()
