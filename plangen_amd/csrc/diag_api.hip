@@ -18,6 +18,7 @@ int pg_diag_set_option(pg_handle h, const char* key, int64_t value) {
     if (!strcmp(key, "split_target_small")) { h->tune.split_small = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "split_target_mid")) { h->tune.split_mid = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "gn_epilogue256")) { h->tune.gn_epilogue256 = value != 0; return PG_OK; }      // GroupNorm partials from the 256x256 conv epilogue (measured slower, profiles/r06_c)
+    if (!strcmp(key, "sk3_xa")) { h->tune.sk3_xa = (int)value; h->tune_epoch++; return PG_OK; }
     if (!strcmp(key, "sk5")) { h->tune.sk5 = value != 0; h->tune_epoch++; return PG_OK; }      // 0: the round-5 v3 blocks for the wide-N decode GEMMs at 65..128 rows (bf16 sums round differently)
     if (!strcmp(key, "defer_norm")) { h->defer_norm = value != 0; h->tune_epoch++; return PG_OK; }      // 0: rmsnorm512 + plain GEMMs at 65..128 rows too (round-5 arithmetic; bf16 rounding differs)
     if (!strcmp(key, "fuse_rope")) { h->fuse_rope = value != 0; h->tune_epoch++; return PG_OK; }

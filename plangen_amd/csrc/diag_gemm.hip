@@ -69,6 +69,20 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         // (tools/sk3_profile.py): 500 gate|up + SwiGLU (S = 1, 16 chunks), 501 qkv (S = 2, 8 chunks), 502 / 503 the same with a ring of 4
         case 500: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 8, true, true>(s, x, W, out, M, N, K, S, SkRowScale{(const float*)g_sk4_prof, 0.f}); return 128;
         case 501: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 2, true, 0, 8, true, true>(s, x, W, out, M, N, K, S, SkRowScale{(const float*)g_sk4_prof, 0.f}); return 128;
+        // x prefetched TWO chunks ahead (XA = 2): 503 stamped gate|up, 504 / 505 plain gate|up + SwiGLU (ring 2 / ring 3), 506 / 507 qkv slabs S = 2 (ring 2 / 3), 508 slab form S = 1
+        case 503: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 8, true, true, 2>(s, x, W, out, M, N, K, S, SkRowScale{(const float*)g_sk4_prof, 0.f}); return 128;
+        case 504: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 8, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
+        case 505: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 3, true, 1, 8, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
+        case 506: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 2, true, 0, 8, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
+        case 507: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 3, true, 0, 8, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
+        case 508: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 0, 8, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
+        case 509: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 8, true, false, 1>(s, x, W, out, M, N, K, S); return 128;      // production gate|up + SwiGLU, unstamped (reference for 504 / 505)
+        // 96-column blocks (6 waves): gate|up 236 blocks, qkv (S = 2) 256 blocks instead of 176 / 192 -- per-CU ingest 640 / 320 KiB instead of 768 / 384
+        case 520: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 6, true, false, 1>(s, x, W, out, M, N, K, S); return 128;
+        case 521: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 2, true, 0, 6, true, false, 1>(s, x, W, out, M, N, K, S); return 128;
+        case 522: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 3, true, 1, 6, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
+        case 523: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 3, true, 0, 6, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
+        case 524: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 4, true, false, 1>(s, x, W, out, M, N, K, S); return 128;      // 64-column blocks: 352
         case 502: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 4, true, 1, 8, true, true>(s, x, W, out, M, N, K, S, SkRowScale{(const float*)g_sk4_prof, 0.f}); return 128;
         // round 6: v5 (n-tile pairs x two K halves, x by LDS-DMA): 510 gate|up + SwiGLU (S = 1), 511 fp32 slabs (qkv S = 2, gen_head / lm_head S = 1)
         case 510: return sk5_try<3>(s, x, W, out, M, N, K, S) ? 128 : 0;

@@ -180,7 +180,9 @@ constexpr int sk3_main_lds(int MT, int NW, bool XDB) {
     const int XL = (XDB ? 2 : 1) * MT * 16 * SK_ROWB, TL = MT * 16 * (NW * 16 + 4) * 4;
     return XL > TL ? XL : TL;
 }
-template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false, bool PROF = false>      // PROF (libplangen_diag.so only): per-wave cycle stamps through the ssq pointer
+// XA (round 6): x prefetch distance in chunks (1 = rounds 1-5).  XA = 2: the staging registers of x(c+2) are loaded at the top of chunk c, so the wait for x(c+1) at the
+// end of chunk c finds it issued a whole chunk earlier AND -- loads return in order -- no longer retires W(c+1), x(c+2), W(c+2), which are all younger.
+template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false, bool PROF = false, int XA = 1>      // PROF (libplangen_diag.so only): per-wave cycle stamps through the ssq pointer
 __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
                                                                float* __restrict__ out, const float* __restrict__ ssq_, int M, int N, int K, int wt, float eps) {
     // ssq (round 6): deferred-1/rms RMSNorm -- x is bf16(residual . w_norm), ssq [M][8] holds 8 partial sums of squares of every residual row
@@ -210,8 +212,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
     constexpr int WCH = TILED ? 2048 : SK_BK, WI = TILED ? 512 : 32;       // element strides per chunk / per k-step
     const bf16* xp = x + kbeg;
 
-    u32x4 xs[XV];
+    static_assert(XA == 1 || XA == 2, "x prefetch distance");
+    u32x4 xsr[XA][XV];
     auto xload = [&](int c) {
+        u32x4 (&xs)[XV] = xsr[c % XA];
 #pragma unroll
         for (int j = 0; j < XV; ++j) {
             const int v = tid + j * NTH, row = v >> 4, cv = v & 15;
@@ -222,12 +226,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
             if constexpr ((MT * 256) % NTH == 0) {
                 xs[j] = *(const u32x4*)(xp + (long)(m < M ? m : M - 1) * K + c * SK_BK + cv * 8);
             } else {
-                if (row < MT * 16) xs[j] = *(const u32x4*)(xp + (long)(m < M ? m : M - 1) * K + c * SK_BK + cv * 8);
-                else xs[j] = (u32x4){0u, 0u, 0u, 0u};
+                // tile does not divide over the block (NW = 6: 1 024 vectors over 384 threads): the surplus threads re-read the tile's last row -- an
+                // UNCONDITIONAL load (round 6; a conditional one costs a vmcnt(0) at the join), dropped by the guarded xstore
+                const int mc = mbase + (row < MT * 16 ? row : MT * 16 - 1);
+                xs[j] = *(const u32x4*)(xp + (long)(mc < M ? mc : M - 1) * K + c * SK_BK + cv * 8);
             }
         }
     };
-    auto xstore = [&](int buf) {
+    auto xstore = [&](int buf, int c) {
+        u32x4 (&xs)[XV] = xsr[c % XA];
 #pragma unroll
         for (int j = 0; j < XV; ++j) {
             const int v = tid + j * NTH, row = v >> 4, cv = v & 15;
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     xload(0);
+    if constexpr (XA == 2 && NCK > 1) xload(1);
     stamp();                                                            // 1: W ring prologue + x chunk 0 issued
     float* const rs = ssq ? (float*)(smem + RS_OFF) : nullptr;
     if (ssq && tid < MT * 16) {                                        // fixed summation order: the scale of a row does not depend on the block that computes it
@@ -253,13 +261,13 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
         const f32x4 a = *(const f32x4*)pp, b = *(const f32x4*)(pp + 4);
         rs[tid] = rsqrtf((((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) / (float)K + eps);
     }
-    xstore(0);
+    xstore(0, 0);
     stamp();                                                            // 2: x chunk 0 arrived and written to LDS
     __syncthreads();
     stamp();                                                            // 3: block barrier
 #pragma unroll
     for (int c = 0; c < NCK; ++c) {
-        if (c + 1 < NCK) xload(c + 1);
+        if (c + XA < NCK) xload(c + XA);
         const char* xt = smem + (XDB ? (c & 1) * XB : 0);
         skinny_mfma_chunk<MT>(xt, lr, g, wr[c % D], acc);
         if constexpr (PROF) stamp();                                    // 4 + 3c: fragment reads + MFMAs of chunk c issued (W(c) was already in registers: the x wait below retires it, loads return in order)
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
         }
         if (c + 1 < NCK) {
             if (!XDB) __syncthreads();
-            xstore(XDB ? ((c + 1) & 1) : 0);
+            xstore(XDB ? ((c + 1) & 1) : 0, c + 1);
             if constexpr (PROF) stamp();                                // 5 + 3c: x(c+1) -- and with it every older load: W(c+1) -- landed, tile written
             __syncthreads();
         } else if constexpr (PROF) stamp();
@@ -281,10 +289,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
 }
 // Deferred-1/rms RMSNorm site handed down the decode GEMM dispatch (round 6): ssq [M][8] partial sums of squares + eps; null = off.
 struct SkRowScale { const float* ssq = nullptr; float eps = 0.f; };
-template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false, bool PROF = false>
+template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false, bool PROF = false, int XA = 1>
 static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, SkRowScale rsc = {}) {
     constexpr int LDS = sk3_main_lds(MT, NW, XDB) + MT * 16 * 4;      // + the row scales (used only with rsc.ssq)
-    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED, PROF>;
+    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED, PROF, XA>;
     (void)PG_DYN_LDS(kfn, LDS);
     dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, rsc.ssq, M, N, K, pg_tune->wt_store & 1, rsc.eps);
@@ -307,6 +315,16 @@ static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out,
 
 
 // ---- production dispatch: v3 (W register ring depth 2, double-buffered x tile) ----
+// x prefetched two chunks ahead, W ring 3 (round 6): the 64-row x 128-column wide-N block whose x wait no longer drains the W ring; same K order = same bits
+template <int EPI>
+static bool sk3_xa2_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck, SkRowScale rsc = {}) {
+    switch (nck) {
+        case 4: launch_sk3<4, 4, 3, true, EPI, 8, true, false, 2>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 8: launch_sk3<4, 8, 3, true, EPI, 8, true, false, 2>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 16: launch_sk3<4, 16, 3, true, EPI, 8, true, false, 2>(s, x, W, out, M, N, K, S, rsc); return true;
+        default: return false;
+    }
+}
 template <int MT, int EPI, int NW = 4, bool TILED = false, int D = 2>
 static bool sk3_prod_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck, SkRowScale rsc = {}) {
     switch (nck) {

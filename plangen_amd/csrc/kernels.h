@@ -29,6 +29,8 @@ struct PgTune {
     int vit_attn = 2;                                           // SigLIP attention: 2 = K / V^T of a head resident in LDS (round 4), 1 = 64-key tile kernel
     int ln_wave = 1;                                            // SigLIP LayerNorm: wave-per-row register kernel (0: generic block-per-row kernel)
     int wt_store = 0;                                           // v3 decode GEMM slabs with write-through (sc1) stores (libplangen_diag.so only)
+    int sk3_xa = 1;                                             // wide-N decode GEMMs at 65..128 rows: x prefetch distance of the v3 8-wave block (2 = two chunks ahead + W ring 3: the x wait no
+                                                                // longer retires the W ring; bit-identical results)
     int sk5 = 0;                                                // 1 (libplangen_diag.so only: the bf16 sums round differently): the v5 kernel for the wide-N decode GEMMs at 65..128 rows (n-tile pairs x
                                                                 // two K halves, x by LDS-DMA; gemm_skinny.h).  Measured in round 6: on par in the microbenchmark, +80 ms per bs=64 step in the loop
                                                                 // (profiles/r06_b) -- NOT the default; kept selectable for A/B

@@ -8,7 +8,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library needs)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(ROOT, "plangen_amd", "lib", "libplangen_diag.so"))
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-N, K, S, NCK = {500: (11264, 2048, 1, 16), 501: (6144, 2048, 2, 8), 502: (11264, 2048, 1, 16)}[v]
+N, K, S, NCK = {500: (11264, 2048, 1, 16), 501: (6144, 2048, 2, 8), 502: (11264, 2048, 1, 16), 503: (11264, 2048, 1, 16)}[v]
 M, maxw = 128, 4096
 buf = np.zeros((maxw, 64), dtype=np.uint64)
 lib.pg_bench_sk4_profile.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int]
