@@ -39,7 +39,7 @@ cat $OUT/${tag}_mfma_counters.md
 } > $OUT/${tag}_sq_counters.md 2>&1
 cat $OUT/${tag}_sq_counters.md
 cd /tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-roofline --no-shard-check --no-rccl-selftest --batch 64 --steps 1 --warmup 0"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-roofline --no-shard-check --no-rccl-selftest --no-secondary --batch 64 --steps 1 --warmup 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/pmc_${tag}_$c
   rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_${tag}_$c -o p -- $BENCH --tokens 24 > $OUT/pmc_${tag}_$c.log 2>&1
