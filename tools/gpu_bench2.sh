@@ -1,12 +1,7 @@
 #!/bin/bash
-# final pass of round 6: class traces on the final sources (for profiles/kernel_classes_b*.json), smoke, the whole GPU suite, the default bench line (twice)
+# the default bench line twice, with its wall time
 tag=${1:-final6}
 mkdir -p gpurun_out
-for b in 64 32 8; do bash tools/trace_batch.sh $b r06_b$b > /dev/null 2>&1; done
-for b in 64 32 8; do python tools/trace_classes.py gpurun_out/trace_r06_b${b}_summary.md $b gpurun_out/kernel_classes_b$b.json; done
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6 | tee gpurun_out/smoke_$tag.log
-python -m pytest tests -m gpu -q --timeout 1500 > gpurun_out/tests_$tag.log 2>&1; echo "pytest rc=$?" | tee -a gpurun_out/tests_$tag.log
-grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/tests_$tag.log | cut -c1-300 | tail -12
 for i in 1 2; do
   t0=$(date +%s); python bench.py > gpurun_out/bench_${tag}_$i.json 2> gpurun_out/bench_${tag}_$i.err; echo "bench rc=$? wall $(( $(date +%s) - t0 )) s"
   python - <<PY
