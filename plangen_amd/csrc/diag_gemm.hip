@@ -82,6 +82,8 @@ int launch_gemm_skinny_variant(hipStream_t s, int variant, const bf16* x, const 
         case 521: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 2, true, 0, 6, true, false, 1>(s, x, W, out, M, N, K, S); return 128;
         case 522: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 3, true, 1, 6, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
         case 523: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 3, true, 0, 6, true, false, 2>(s, x, W, out, M, N, K, S); return 128;
+        case 530: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 8, true, false, 1, true>(s, x, W, out, M, N, K, S); return 128;      // production gate|up + SwiGLU with nt weight loads
+        case 531: if (S != 2 || K != 2048) return 0; launch_sk3<4, 8, 2, true, 0, 8, true, false, 1, true>(s, x, W, out, M, N, K, S); return 128;       // qkv with nt weight loads
         case 524: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 2, true, 1, 4, true, false, 1>(s, x, W, out, M, N, K, S); return 128;      // 64-column blocks: 352
         case 502: if (S != 1 || K != 2048) return 0; launch_sk3<4, 16, 4, true, 1, 8, true, true>(s, x, W, out, M, N, K, S, SkRowScale{(const float*)g_sk4_prof, 0.f}); return 128;
         // round 6: v5 (n-tile pairs x two K halves, x by LDS-DMA): 510 gate|up + SwiGLU (S = 1), 511 fp32 slabs (qkv S = 2, gen_head / lm_head S = 1)

@@ -311,7 +311,10 @@ static bool sk3_prod_tiled(hipStream_t s, const bf16* x, const bf16* Wt, float* 
     // wide N (qkv, gate|up, gen_head at 65..128 rows): 128-column blocks of 8 waves -- the x tile is fetched and staged once per 128
     // columns instead of once per 64 (loop -11 ms at bs=64); stream_gemm bit 128 keeps the 4-wave block for A/B
     if (N % 128 == 0 && N >= 4096 && !(pg_tune->stream_gemm >= 0 && (pg_tune->stream_gemm & 128))) {
-        if constexpr (TILED) { if (pg_tune->sk3_xa == 2 && sk3_xa2_nck<EPI>(s, x, Wt, out, M, N, K, S, nck, rsc)) return true; }
+        if constexpr (TILED) {
+            if (pg_tune->sk3_xa == 2 && sk3_xa2_nck<EPI>(s, x, Wt, out, M, N, K, S, nck, rsc)) return true;
+            if (pg_tune->sk3_xa == 3 && sk3_nt_nck<EPI>(s, x, Wt, out, M, N, K, S, nck, rsc)) return true;       // round 6 experiment: nt hint on the weight fragments
+        }
         return sk3_prod_nck<4, EPI, 8, TILED>(s, x, Wt, out, M, N, K, S, nck, rsc);
     }
     return sk3_prod_nck<4, EPI, 4, TILED>(s, x, Wt, out, M, N, K, S, nck, rsc);

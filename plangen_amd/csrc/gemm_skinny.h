@@ -182,7 +182,8 @@ constexpr int sk3_main_lds(int MT, int NW, bool XDB) {
 }
 // XA (round 6): x prefetch distance in chunks (1 = rounds 1-5).  XA = 2: the staging registers of x(c+2) are loaded at the top of chunk c, so the wait for x(c+1) at the
 // end of chunk c finds it issued a whole chunk earlier AND -- loads return in order -- no longer retires W(c+1), x(c+2), W(c+2), which are all younger.
-template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false, bool PROF = false, int XA = 1>      // PROF (libplangen_diag.so only): per-wave cycle stamps through the ssq pointer
+// NTW (round 6 experiment): the weight fragments with the non-temporal hint (the v4 kernels' `nt`); every W tile here is read by TWO row blocks.
+template <int MT, int NCK, int D, bool XDB, int EPI, int NW, bool TILED = false, bool PROF = false, int XA = 1, bool NTW = false>      // PROF (libplangen_diag.so only): per-wave cycle stamps through the ssq pointer
 __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ W,
                                                                float* __restrict__ out, const float* __restrict__ ssq_, int M, int N, int K, int wt, float eps) {
     // ssq (round 6): deferred-1/rms RMSNorm -- x is bf16(residual . w_norm), ssq [M][8] holds 8 partial sums of squares of every residual row
@@ -243,11 +244,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
             if ((MT * 256) % NTH == 0 || row < MT * 16) *(u32x4*)(smem + buf * XB + row * SK_ROWB + cv * 16) = xs[j];
         }
     };
+    auto wld = [&](const bf16* p) __attribute__((always_inline)) -> bf16x8 {
+        if constexpr (NTW) return __builtin_nontemporal_load((const bf16x8*)p);
+        else return *(const bf16x8*)p;
+    };
     bf16x8 wr[D][4];
 #pragma unroll
     for (int c = 0; c < D && c < NCK; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wr[c][i] = *(const bf16x8*)(wp + c * WCH + i * WI);
+        for (int i = 0; i < 4; ++i) wr[c][i] = wld(wp + c * WCH + i * WI);
     f32x4 acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
         if constexpr (PROF) stamp();                                    // 4 + 3c: fragment reads + MFMAs of chunk c issued (W(c) was already in registers: the x wait below retires it, loads return in order)
         if (c + D < NCK) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wr[c % D][i] = *(const bf16x8*)(wp + (c + D) * WCH + i * WI);
+            for (int i = 0; i < 4; ++i) wr[c % D][i] = wld(wp + (c + D) * WCH + i * WI);
         }
         if (c + 1 < NCK) {
             if (!XDB) __syncthreads();
@@ -289,10 +294,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_skinny3_kernel(const bf16* __
 }
 // Deferred-1/rms RMSNorm site handed down the decode GEMM dispatch (round 6): ssq [M][8] partial sums of squares + eps; null = off.
 struct SkRowScale { const float* ssq = nullptr; float eps = 0.f; };
-template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false, bool PROF = false, int XA = 1>
+template <int MT, int NCK, int D, bool XDB, int EPI = 0, int NW = 4, bool TILED = false, bool PROF = false, int XA = 1, bool NTW = false>
 static void launch_sk3(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, SkRowScale rsc = {}) {
     constexpr int LDS = sk3_main_lds(MT, NW, XDB) + MT * 16 * 4;      // + the row scales (used only with rsc.ssq)
-    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED, PROF, XA>;
+    auto kfn = gemm_skinny3_kernel<MT, NCK, D, XDB, EPI, NW, TILED, PROF, XA, NTW>;
     (void)PG_DYN_LDS(kfn, LDS);
     dim3 grid((N + 16 * NW - 1) / (16 * NW), S, (M + MT * 16 - 1) / (MT * 16)), block(64 * NW);
     hipLaunchKernelGGL(kfn, grid, block, LDS, s, x, W, out, rsc.ssq, M, N, K, pg_tune->wt_store & 1, rsc.eps);
@@ -316,6 +321,15 @@ static int sk3_dispatch(hipStream_t s, const bf16* x, const bf16* W, float* out,
 
 // ---- production dispatch: v3 (W register ring depth 2, double-buffered x tile) ----
 // x prefetched two chunks ahead, W ring 3 (round 6): the 64-row x 128-column wide-N block whose x wait no longer drains the W ring; same K order = same bits
+template <int EPI>
+static bool sk3_nt_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck, SkRowScale rsc = {}) {      // production block, W with the nt hint
+    switch (nck) {
+        case 4: launch_sk3<4, 4, 2, true, EPI, 8, true, false, 1, true>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 8: launch_sk3<4, 8, 2, true, EPI, 8, true, false, 1, true>(s, x, W, out, M, N, K, S, rsc); return true;
+        case 16: launch_sk3<4, 16, 2, true, EPI, 8, true, false, 1, true>(s, x, W, out, M, N, K, S, rsc); return true;
+        default: return false;
+    }
+}
 template <int EPI>
 static bool sk3_xa2_nck(hipStream_t s, const bf16* x, const bf16* W, float* out, int M, int N, int K, int S, int nck, SkRowScale rsc = {}) {
     switch (nck) {
