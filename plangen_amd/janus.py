@@ -117,6 +117,9 @@ class _GenVisionModel:
         if shape is not None and (shape[1] != cfg.img_dim or shape[2] != cfg.grid or shape[3] != cfg.grid):
             raise PlanGenError(f"decode_code: shape {list(shape)} does not match the configured VQ ({cfg.img_dim},{cfg.grid},{cfg.grid})")
         if not channel_first:
+            # vq_model.py:297-298: channel_first=False makes get_codebook_entry return z_q.view(shape) with shape = (B, H, W, C) -- an NHWC tensor that
+            # the reference's own decode() then feeds to post_quant_conv (a Conv2d over dim 1): with H = W = 24 != 8 channels it raises there.  The only call
+            # in the reference passes channel_first=True (plangen_base.py:555); refusing the other form is the reference's error behaviour, stated up front.
             raise PlanGenError("decode_code: only channel_first=True (the reference's call) is supported")
         B = shape[0] if shape is not None else code_b.shape[0]
         return self.eng.vq_decode(code_b.reshape(B, -1))
