@@ -32,10 +32,175 @@
 #define CH_HALO_BYTES (88 * 1024)               // 88 wave-instructions x 1 KiB (>= 340 x 256 B)
 #define CH_WSLOT 16384                          // one K tile of weights: 128 rows x 128 B
 #define CH_RED (CH_HALO_BYTES + 4 * CH_WSLOT)       // 1 KiB: per-wave GroupNorm partials of the epilogue
-#define CH_LDS (CH_RED + 1024)
+#define CH_BIAS (CH_RED + 1024)                 // 512 B: the 128 per-channel biases (fast epilogue), staged once per block
+#define CH_LDS (CH_BIAS + 512)
 #define CH_NKT 18                               // 9 taps x (128 / 64)
 
-template <class EP, bool STAG, bool UP>
+// TEMP instrumentation
+__device__ unsigned long long g_halo_prof[2 * 64 * 8];
+bool halo_prof_read(unsigned long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_prof), sizeof(g_halo_prof)) == hipSuccess; }
+__device__ unsigned long long g_halo_prof2[2 * 18 * 8];
+bool halo_prof2_read(unsigned long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_prof2), sizeof(g_halo_prof2)) == hipSuccess; }
+#define PSTAMP(t, k) if constexpr (PROF) { if (blockIdx.x == 7 && (w & 3) == 0 && l == 0 && pit == 20) g_halo_prof2[((w >> 2) * 18 + (t)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); }
+#define HSTAMP(k) if constexpr (PROF) { if (blockIdx.x == 7 && (w & 3) == 0 && l == 0 && pit < 64) g_halo_prof[((w >> 2) * 64 + pit) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); }
+
+// Epilogue of one 8 x 32 tile, shared by the two halo kernels: a wave's 4 x 4 f32x4 accumulators (m-tile mt = pixel row pair / 16-pixel half, n-tile nt = 16
+// output channels) through the shared Epi in two batches of 8 fragments; with gn_part the GroupNorm(32 groups of 4 channels) partial sums of the STORED values.
+template <class EP>
+__device__ __forceinline__ void halo_epilogue(const EP& ep, f32x4 (&acc)[4][4], long mrow, int Wd, int tile_id, bool vec, float* __restrict__ gn_part,
+                                              float* red, int tid, int w, int wc, int g, int lr) {
+    if (gn_part && vec) {
+        // GroupNorm(32 groups of 4 channels) statistics of the values being stored: a lane's f32x4 is one
+        // group of one pixel.  Fixed-order reduction: 4 m-tiles in registers, 16 pixel lanes by shuffles,
+        // the 4 pixel-row waves through LDS -> one (sum, sum of squares) per (tile, group); the finalize
+        // kernel adds the tiles of an image in double.  Replaces the separate statistics pass.
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {                                // 8 fragments per batch: all bias / residual loads up front
+            int rows[8], cols[8]; f32x4 av[8], vo[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int mt = mp * 2 + (i >> 2), nt = i & 3;
+                rows[i] = (int)(mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16); cols[i] = wc * 64 + nt * 16 + g * 4; av[i] = acc[mt][nt];
+            }
+            ep.template store4_batch<8>(0, 0, rows, cols, av, true, vo);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int nt = i & 3;
+                const f32x4 v = vo[i];
+                s1[nt] += (v[0] + v[1]) + (v[2] + v[3]);
+                s2[nt] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1[nt] += __shfl_xor(s1[nt], o, 64); s2[nt] += __shfl_xor(s2[nt], o, 64); }
+        if (lr == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { red[(w * 16 + nt * 4 + g) * 2] = s1[nt]; red[(w * 16 + nt * 4 + g) * 2 + 1] = s2[nt]; }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int gwc = tid >> 4, gi = tid & 15;                    // group = gwc*16 + gi
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { a += red[((r4 * 2 + gwc) * 16 + gi) * 2]; q += red[((r4 * 2 + gwc) * 16 + gi) * 2 + 1]; }
+            gn_part[((long)tile_id * 32 + tid) * 2] = a; gn_part[((long)tile_id * 32 + tid) * 2 + 1] = q;
+        }
+        __syncthreads();                                            // red is rewritten by the next tile
+    } else {
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+            int rows[8], cols[8]; f32x4 av[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int mt = mp * 2 + (i >> 2), nt = i & 3;
+                rows[i] = (int)(mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16); cols[i] = wc * 64 + nt * 16 + g * 4; av[i] = acc[mt][nt];
+            }
+            ep.template store4_batch<8>(0, 0, rows, cols, av, vec);
+        }
+    }
+}
+
+
+// Round 6: the epilogue without a wait behind its first store.  One s_waitcnt vmcnt(N) covers loads AND stores of a wave in issue order, so the generic epilogue above
+// -- two batches of [bias loads, residual loads, wait, 8 stores] -- waited, in its second batch, for the write acknowledgements of the first (and in its first, for the
+// next tile's halo fill issued in front of it): 6-10 us of a 20-24 us tile with the MFMA pipe idle (stamps: profiles/r06_c_vq_decode.md).  Here the bias (4 x f32x4 per
+// lane, the same for every tile) is loaded once per kernel, all 16 residual loads of a tile are issued first (halo_epi_loads, BEFORE the next tile's fill goes out) and
+// the 16 stores follow with nothing to wait for.  Same arithmetic and order as Epi::store4 (scale, bias, residual), same GroupNorm partial sums.
+// Taken when the layout is the vector one and there is no bias_m / activation (every convolution of the decoder); halo_epilogue otherwise.
+
+// Addressing: one wave-uniform 64-bit base per tile (its first pixel) + a 32-bit per-lane byte offset per m-tile (a tile spans 8 image rows: < 2^31 bytes), so the 16
+// accesses of a tile need 4 offset registers, not 16 64-bit pointers.  trow0 = index of the tile's first pixel, lrow = (wr*2)*Wd + lr.
+template <int RES, class EP>
+__device__ __forceinline__ void halo_epi_loads(const EP& ep, long trow0, int lrow, int Wd, int wc, int g, f32x4 (&r)[4][4]) {
+    const auto& e = ep.e;
+    if constexpr (RES == 0) return;
+    const int ldr = (int)(e.ldr ? e.ldr : e.ldc);
+    constexpr int esz = RES == 1 ? 4 : 2;
+    const char* const base = (const char*)e.residual + trow0 * ldr * esz;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const unsigned off = (unsigned)(((lrow + (mt >> 1) * Wd + (mt & 1) * 16) * ldr + wc * 64 + g * 4) * esz);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if constexpr (RES == 1) r[mt][nt] = *(const f32x4*)(base + off + nt * 64);
+            else {
+                const uint2 r2 = *(const uint2*)(base + off + nt * 32);
+                r[mt][nt] = (f32x4){__uint_as_float(r2.x), __uint_as_float(r2.y), 0.f, 0.f};        // bf16 pairs, decoded at the use
+            }
+        }
+    }
+}
+
+template <bool GN, int RES, bool OF32, class EP>
+__device__ __forceinline__ void halo_epi_stores_impl(const EP& ep, f32x4 (&acc)[4][4], const f32x4 (&bias)[4], f32x4 (&r)[4][4], long trow0, int lrow, int Wd, int tile_id,
+                                                     float* __restrict__ gn_part, float* red, int tid, int w, int wc, int g, int lr) {
+    const auto& e = ep.e;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ldc = (int)e.ldc;
+    constexpr int esz = OF32 ? 4 : 2;
+    char* const base = (char*)e.out + trow0 * ldc * esz;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const unsigned off = (unsigned)(((lrow + (mt >> 1) * Wd + (mt & 1) * 16) * ldc + wc * 64 + g * 4) * esz);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[mt][nt];
+            v *= e.scale;
+            v += bias[nt];
+            if constexpr (RES == 1) v += r[mt][nt];
+            else if constexpr (RES == 2) {
+                const unsigned a = __float_as_uint(r[mt][nt][0]), b2 = __float_as_uint(r[mt][nt][1]);
+                v += (f32x4){bf16_lo(a), bf16_hi(a), bf16_lo(b2), bf16_hi(b2)};
+            }
+            if constexpr (OF32) *(f32x4*)(base + off + nt * 64) = v;
+            else { uint2 q; q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); *(uint2*)(base + off + nt * 32) = q; }
+            if constexpr (GN) {
+                s1[nt] += (v[0] + v[1]) + (v[2] + v[3]);
+                s2[nt] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            }
+        }
+    }
+    if constexpr (GN) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1[nt] += __shfl_xor(s1[nt], o, 64); s2[nt] += __shfl_xor(s2[nt], o, 64); }
+        if (lr == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { red[(w * 16 + nt * 4 + g) * 2] = s1[nt]; red[(w * 16 + nt * 4 + g) * 2 + 1] = s2[nt]; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // LDS only: __syncthreads() would also wait for this tile's stores and the next tile's fill (vmcnt(0))
+        if (tid < 32) {
+            const int gwc = tid >> 4, gi = tid & 15;
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { a += red[((r4 * 2 + gwc) * 16 + gi) * 2]; q += red[((r4 * 2 + gwc) * 16 + gi) * 2 + 1]; }
+            gn_part[((long)tile_id * 32 + tid) * 2] = a; gn_part[((long)tile_id * 32 + tid) * 2 + 1] = q;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // red is rewritten by the next tile
+    }
+}
+template <int RES, bool OF32, class EP>
+__device__ __forceinline__ void halo_epi_stores(const EP& ep, f32x4 (&acc)[4][4], const f32x4 (&bias)[4], f32x4 (&r)[4][4], long trow0, int lrow, int Wd, int tile_id,
+                                                float* __restrict__ gn_part, float* red, int tid, int w, int wc, int g, int lr) {
+    if (gn_part) halo_epi_stores_impl<true, RES, OF32>(ep, acc, bias, r, trow0, lrow, Wd, tile_id, gn_part, red, tid, w, wc, g, lr);
+    else halo_epi_stores_impl<false, RES, OF32>(ep, acc, bias, r, trow0, lrow, Wd, tile_id, gn_part, red, tid, w, wc, g, lr);
+}
+// the 128 biases to LDS once per block (thread c < 128 stores bias[c]); a tile's epilogue reads its 4 x f32x4 back (4 ds_read_b128) instead of holding 16 registers
+// through the MFMA loop.  Visible to every wave after the first block barrier of the kernel.
+template <class EP>
+__device__ __forceinline__ void halo_bias_stage(const EP& ep, bool fast, int tid, float* lds_bias) {
+    if (fast && tid < 128) lds_bias[tid] = ep.e.bias_n[tid];
+}
+__device__ __forceinline__ void halo_bias_read(const float* lds_bias, int wc, int g, f32x4 (&bias)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = *(const f32x4*)(lds_bias + wc * 64 + nt * 16 + g * 4);
+}
+
+template <class EP, bool STAG, bool UP, bool PROF = false, int PD = 2, int EPK = -1, int WI = 2>     // WI = 1: TEMP experiment, half the weight stream (wrong results)      // EPK: -1 generic epilogue; else residual kind (0 none, 1 fp32, 2 bf16) * 2 + (fp32 output)
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt,
                                                           const bf16* __restrict__ zeros, EP ep, int B, int H, int Wd,
                                                           float* __restrict__ gn_part) {
@@ -49,6 +214,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
     const int tiles_x = Wd / CH_TW, tiles_y = H / CH_TH, tiles_img = tiles_x * tiles_y;
     const int NT = tiles_img * B, G = gridDim.x;
     const bool vec = ep.vec_ok(0, 0);
+    constexpr bool fast = EPK >= 0;                                 // host-checked: vector layout, bias_n, no bias_m / activation (conv_halo_try)
+    constexpr int RES = EPK >= 0 ? EPK / 2 : 0; constexpr bool OF32 = EPK >= 0 && (EPK & 1);
+    float* const lds_bias = (float*)(smem + CH_BIAS);
+    halo_bias_stage(ep, fast, tid, lds_bias);
 
     // weight staging: wave w, instruction i covers LDS rows (i*8 + w)*8 .. +7 (row = output channel)
     const int wsrow = w * 8 + (l >> 3);
@@ -59,7 +228,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
         const int tt = t < CH_NKT ? t : CH_NKT - 1;                            // clamped tail: keeps the counts exact
         char* d = wlds + (t & 3) * CH_WSLOT + w * 1024;
         glds16(wsrc0 + tt * 64, d);
-        glds16(wsrc1 + tt * 64, d + 8192);
+        if constexpr (WI == 2) glds16(wsrc1 + tt * 64, d + 8192);
     };
     // B (weight) fragment addresses inside a slot
     const int swz = (lr >> 1) & 7;
@@ -80,11 +249,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
         const int Hs = UP ? H / 2 : H, Ws = UP ? Wd / 2 : Wd;                    // source image
         const int sy0 = (UP ? y0 / 2 : y0) - 1, sx0 = (UP ? x0 / 2 : x0) - 1;      // source coords of halo pixel (0, 0)
         const bf16* img = X + (long)b * Hs * Ws * 128;
+        int ll = l;
+        asm volatile("" : "+v"(ll));                                           // per-lane halo coordinates are recomputed per tile, not kept in 20+ registers through the MFMA loop
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int q = j * 8 + w;                                           // wave-instruction index, 1 KiB each
-            int hp = q * 4 + (l >> 4);
-            const int pos = l & 15;
+            int hp = q * 4 + (ll >> 4);
+            const int pos = ll & 15;
             const bool inr = hp < NHP;
             hp = inr ? hp : NHP - 1;
             const int hy = hp / HWD, hx = hp - hy * HWD;
@@ -95,11 +266,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
             glds16(src, halo + q * 1024);
         }
         stage_w(0); stage_w(1);
-        if (!STAG) stage_w(2);
+        if (!STAG || PD == 3) stage_w(2);
     };
-    int tix = blockIdx.x;
+    int tix = blockIdx.x; int pit = 0;
+    bool lazy = false;                                              // fast epilogue of the PREVIOUS tile: 16 stores sit between W(PD-1) and W(PD) in this wave's queue
     if (tix < NT) fill(tix);
     while (tix < NT) {
+        HSTAMP(0)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -113,11 +286,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
             // Round 3: the halo and W(0) are retired here and read by the first wave group right behind the barrier -- the same-phase
             // form the staging rule forbids (tools/dma_isa_check.py) -- so a second barrier separates retirement from the first read
             // (once per 8x32 tile; both groups pass it, the barrier counts stay equal).
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            // Round 6: W(1..PD-1) may fly, and so may the previous tile's 16 epilogue stores (issued BEHIND the fill: waiting for them here was 1.5 us per tile)
+            if (lazy) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WI * (PD - 1) + 16) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WI * (PD - 1)) : "memory");
             asm volatile("s_barrier" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
             if (wr >= 2) asm volatile("s_barrier" ::: "memory");
         }
+        HSTAMP(1)
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
@@ -139,6 +315,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
                     asm volatile("s_barrier" ::: "memory");                    // round 3: retirement and first read one barrier apart (staging rule, strict form)
                     stage_w(t + 3);                                            // slot of tile t-1: every wave is past its reads
                 }
+                PSTAMP(t, 0)
                 const char* ws = wlds + (t & 3) * CH_WSLOT;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
@@ -151,12 +328,21 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
                     af[mt][1] = *(const bf16x8*)(halo + (abase[mt] ^ ((kh * 2 + 1) << 6)));
                 }
                 if constexpr (STAG) {
-                    stage_w(t + 2);
-                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    // W(t+PD) goes into the slot read in phase t+PD-4: PD = 2 two phases back; PD = 3 the PREVIOUS phase's slot, which the trailing group read one
+                    // barrier ago -- so with PD = 3 every wave drains its fragment reads (lgkmcnt(0)) in FRONT of the barrier (the gemm256 rule).
+                    PSTAMP(t, 1)
+                    stage_w(t + PD);
+                    // W(t+1) landed.  In the first PD-1 phases of a tile it is OLDER than the previous tile's 16 stores, which may therefore stay in flight.
+                    if (lazy && t <= PD - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WI * (PD - 1) + 16) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WI * (PD - 1)) : "memory");
+                    PSTAMP(t, 2)
+                    if constexpr (PD == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_barrier" ::: "memory");
                 }
+                PSTAMP(t, 3)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PSTAMP(t, 4)
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -168,9 +354,12 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                PSTAMP(t, 5)
                 if constexpr (STAG) asm volatile("s_barrier" ::: "memory");
+                PSTAMP(t, 6)
             }
         }
+        HSTAMP(2)
         if (STAG && wr < 2) asm volatile("s_barrier" ::: "memory");
         // every wave must be done with the halo before the next tile's fill overwrites it; the fill (and the
         // first weight tiles) then go out BEFORE this tile's stores so they fly during the epilogue
@@ -178,63 +367,207 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
         const long mrow = ((long)b * H + y0 + wr * 2) * Wd + x0 + lr;
         const int tile_id = tix;                                        // (image, tile) index of THIS tile
         tix += G;
-        if (tix < NT) fill(tix);
-        if (gn_part && vec) {
-            // GroupNorm(32 groups of 4 channels) statistics of the values being stored: a lane's f32x4 is one
-            // group of one pixel.  Fixed-order reduction: 4 m-tiles in registers, 16 pixel lanes by shuffles,
-            // the 4 pixel-row waves through LDS -> one (sum, sum of squares) per (tile, group); the finalize
-            // kernel adds the tiles of an image in double.  Replaces the separate statistics pass.
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int mp = 0; mp < 2; ++mp) {                                // 8 fragments per batch: all bias / residual loads up front
-                int rows[8], cols[8]; f32x4 av[8], vo[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int mt = mp * 2 + (i >> 2), nt = i & 3;
-                    rows[i] = (int)(mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16); cols[i] = wc * 64 + nt * 16 + g * 4; av[i] = acc[mt][nt];
-                }
-                ep.template store4_batch<8>(0, 0, rows, cols, av, true, vo);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int nt = i & 3;
-                    const f32x4 v = vo[i];
-                    s1[nt] += (v[0] + v[1]) + (v[2] + v[3]);
-                    s2[nt] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1[nt] += __shfl_xor(s1[nt], o, 64); s2[nt] += __shfl_xor(s2[nt], o, 64); }
-            if (lr == 0) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) { red[(w * 16 + nt * 4 + g) * 2] = s1[nt]; red[(w * 16 + nt * 4 + g) * 2 + 1] = s2[nt]; }
-            }
-            __syncthreads();
-            if (tid < 32) {
-                const int gwc = tid >> 4, gi = tid & 15;                    // group = gwc*16 + gi
-                float a = 0.f, q = 0.f;
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) { a += red[((r4 * 2 + gwc) * 16 + gi) * 2]; q += red[((r4 * 2 + gwc) * 16 + gi) * 2 + 1]; }
-                gn_part[((long)tile_id * 32 + tid) * 2] = a; gn_part[((long)tile_id * 32 + tid) * 2 + 1] = q;
-            }
-            __syncthreads();                                            // red is rewritten by the next tile
+        HSTAMP(3)
+        if constexpr (fast) {
+            const long trow0 = __builtin_amdgcn_readfirstlane((int)(((long)b * H + y0) * Wd + x0 >> 31)) * (1L << 31) + __builtin_amdgcn_readfirstlane((int)((((long)b * H + y0) * Wd + x0) & 0x7fffffff));
+            int lrow = wr * 2 * Wd + lr;
+            asm volatile("" : "+v"(lrow));                            // the 8 per-lane byte offsets are recomputed per tile instead of living (as 64-bit values) through the MFMA loop
+            f32x4 bias[4], rres[4][4];
+            // the next tile's fill (and first weight tiles) go out first and fly under the residual loads and the stores; with a residual its wait covers the fill
+            // too (one counter, issue order), which costs little: both come from HBM at the same time.  Nothing is waited for behind the first store.
+            if (tix < NT) fill(tix);
+            __builtin_amdgcn_sched_barrier(0);                          // the fill's address registers die here, before 64 residual registers come alive
+            halo_epi_loads<RES>(ep, trow0, lrow, Wd, wc, g, rres);
+            if constexpr (RES != 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) the compiler can see on EVERY path: otherwise it guards the MFMA loop's first register write with its own (and waits there for the stores)
+            halo_bias_read(lds_bias, wc, g, bias);
+            halo_epi_stores<RES, OF32>(ep, acc, bias, rres, trow0, lrow, Wd, tile_id, gn_part, red, tid, w, wc, g, lr);
+            lazy = true;
         } else {
-#pragma unroll
-            for (int mp = 0; mp < 2; ++mp) {
-                int rows[8], cols[8]; f32x4 av[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int mt = mp * 2 + (i >> 2), nt = i & 3;
-                    rows[i] = (int)(mrow + (long)(mt >> 1) * Wd + (mt & 1) * 16); cols[i] = wc * 64 + nt * 16 + g * 4; av[i] = acc[mt][nt];
-                }
-                ep.template store4_batch<8>(0, 0, rows, cols, av, vec);
-            }
+            if (tix < NT) fill(tix);
+            halo_epilogue(ep, acc, mrow, Wd, tile_id, vec, gn_part, red, tid, w, wc, g, lr);
         }
+        HSTAMP(4)
+        ++pit;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ------------------------------------------------------------------------------- round 6: the halo as two CHANNEL halves, ping-pong
+// conv3x3_halo_kernel serialises, per 8 x 32 tile and CU, [halo fill + epilogue stores drain] -> [18 K tiles of MFMA]: with one 85 KiB patch per CU there is
+// nowhere to receive the next tile's patch while this tile's MFMAs read the current one (19.7 us per tile at 384^2, 7.7 us of it MFMA at full rate).  A second
+// SPATIAL patch does not fit (2 x 85 KiB + the weight ring > 160 KiB) and halving the tile doubles the weight stream.  Splitting the patch by INPUT CHANNEL does fit:
+//   half A = channels 0..63 of the (8+2) x (32+2) patch, half B = channels 64..127: 2 x 42.5 KiB = the same 85 KiB.
+//   K order (half, tap, 64 channels) instead of (tap, 128 channels): phases 0..8 read only half A, phases 9..17 only half B.
+//   => half A of tile i+1 is filled while phases 9..17 of tile i run (issued in phase 9, needed after the epilogue), half B of tile i+1 while the epilogue of tile i and
+//      phases 0..8 of tile i+1 run (issued behind the epilogue, needed in phase 9): no halo byte is waited for within ~4 us of its issue.
+// VMEM operations retire in issue order, so a wave that streams weights with counted waits (one K tile every ~0.5 us) cannot also carry a halo fill that should
+// fly for microseconds.  The two wave groups of the staggered schedule therefore split the ROLES: the leading group (waves 0..3) stages the whole weight tile
+// (4 LDS-DMA instructions per wave per phase, s_waitcnt vmcnt(4)), the trailing group (waves 4..7) issues the halo halves (11 instructions per wave per half) and waits
+// for them with vmcnt(0) seven phases later (phase 16 for half A, phase 7 for half B) -- its queue holds nothing else but its own epilogue's accesses.
+// Barriers per tile: leading 18 x 2 + 1 (re-align at the end), trailing 1 (start, one barrier behind) + 18 x 2.  Every staged piece is retired (vmcnt + barrier) at
+// least two barriers before its first read, every slot re-staged at least two barriers after its last read (tools/dma_isa_check.py, kind halo_pp).
+//   half layout: [halo pixel hp][8 chunks of 16 B], chunk position XOR (hp & 7) through the DMA's source address: a ds_read_b128 lane group (16 pixels, two
+//   k-groups -- MI355X_MICROARCH.md LDS table) touches 16 distinct 16-byte slots for every pixel alignment (the 256-byte layout of the kernel above pays 2 x for odd dx).
+// The accumulation order differs from the im2col kernels' (same products, other order of the 36 partial sums per output): equal to the kernel above to fp32
+// re-association, bit-identical to it when one channel half of the input is zero (tests/test_gpu_ops.py).
+#define C2_HALF (44 * 1024)
+
+template <class EP, bool UP, bool PROF = false, int EPK = -1>
+__global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt, const bf16* __restrict__ zeros, EP ep, int B,
+                                                           int H, int Wd, float* __restrict__ gn_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const halo = smem;
+    char* const wlds = smem + CH_HALO_BYTES;
+    float* const red = (float*)(smem + CH_RED);
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1, g = l >> 4, lr = l & 15;
+    const bool lead = w < 4;
+    const int tiles_x = Wd / CH_TW, tiles_y = H / CH_TH, tiles_img = tiles_x * tiles_y;
+    const int NT = tiles_img * B, G = gridDim.x;
+    const bool vec = ep.vec_ok(0, 0);
+    constexpr bool fast = EPK >= 0;
+    constexpr int RES = EPK >= 0 ? EPK / 2 : 0; constexpr bool OF32 = EPK >= 0 && (EPK & 1);
+    float* const lds_bias = (float*)(smem + CH_BIAS);
+    halo_bias_stage(ep, fast, tid, lds_bias);
+    bool lazy = false;
+
+    // weights (leading group): wave w, instruction i covers LDS rows ((i*4 + w)*8 .. +7) of the 128-row tile; K tile tt = half*9 + tap
+    const int wsrow = (w & 3) * 8 + (l >> 3);
+    const int wsc = ((l & 7) ^ (((w & 1) << 2) + (l >> 4))) * 8;
+    const bf16* const wsrc = Wt + (long)wsrow * (9 * 128) + wsc;
+    auto stage_w = [&](int tt, int slot) __attribute__((always_inline)) {
+        const int hh = tt >= 9 ? 1 : 0;
+        const bf16* src = wsrc + (tt - 9 * hh) * 128 + hh * 64;
+        char* d = wlds + slot * CH_WSLOT + (w & 3) * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(src + (long)i * 32 * (9 * 128), d + i * 4096);
+    };
+    // halo half hh of tile tx (trailing group): wave-instruction q = 8 halo pixels x 8 chunks
+    auto fill_half = [&](int tx, int hh) __attribute__((always_inline)) {
+        const int fb = tx / tiles_img;
+        const int r = tx - fb * tiles_img;
+        const int fy0 = (r / tiles_x) * CH_TH, fx0 = (r % tiles_x) * CH_TW;
+        constexpr int HWD = UP ? CH_TW / 2 + 2 : CH_HW, NHP = UP ? (CH_TH / 2 + 2) * HWD : CH_HP, NJ = UP ? 4 : 11, NQ = (NHP + 7) / 8;
+        const int Hs = UP ? H / 2 : H, Ws = UP ? Wd / 2 : Wd;
+        const int sy0 = (UP ? fy0 / 2 : fy0) - 1, sx0 = (UP ? fx0 / 2 : fx0) - 1;
+        const bf16* img = X + (long)fb * Hs * Ws * 128 + hh * 64;
+        char* const dst = halo + hh * C2_HALF;
+        int ll = l;
+        asm volatile("" : "+v"(ll));                                           // recomputed per fill, not held through the MFMA loop
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int q = j * 4 + (w & 3);
+            q = q < NQ ? q : NQ - 1;                                            // surplus instructions repeat the last one (same bytes to the same place)
+            int hp = q * 8 + (ll >> 3);
+            const int pos = ll & 7;
+            const bool inr = hp < NHP;
+            hp = inr ? hp : NHP - 1;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = sy0 + hy, x = sx0 + hx;
+            const bool ok = inr && y >= 0 && y < Hs && x >= 0 && x < Ws;
+            const int sch = pos ^ (hp & 7);
+            const bf16* src = ok ? img + ((long)y * Ws + x) * 128 + sch * 8 : zeros + sch * 8;
+            glds16(src, dst + q * 1024);
+        }
+    };
+    const int swz = (lr >> 1) & 7;
+    const int boff0 = (wc * 64 + lr) * 128 + ((g ^ swz) << 4), boff1 = boff0 ^ 64;
+    const int hp0 = (wr * 2) * CH_HW + lr;
+
+    f32x4 acc[4][4];
+    bf16x8 af[4][2], bfr[4][2];
+
+    int tix = blockIdx.x, ring = 0, pit = 0;
+    if (tix < NT) {
+        if (lead) { stage_w(0, 0); stage_w(1, 1); }
+        else { fill_half(tix, 0); fill_half(tix, 1); }
+    }
+    if (lead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   // W(0); W(1) is retired by phase 0's wait
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // both halves of the first tile
+    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    while (tix < NT) {
+        const int b = tix / tiles_img;
+        const int rr = tix - b * tiles_img;
+        const int y0 = (rr / tiles_x) * CH_TH, x0 = (rr % tiles_x) * CH_TW;
+        const long mrow = ((long)b * H + y0 + wr * 2) * Wd + x0 + lr;
+        const int nxt = tix + G;
+        HSTAMP(0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!lead) asm volatile("s_barrier" ::: "memory");                       // trailing group: one barrier behind for the whole tile
+        HSTAMP(1)
+#pragma unroll 1
+        for (int t = 0; t < CH_NKT; ++t) {
+            const int hh = t >= 9 ? 1 : 0, tap = t - 9 * hh;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const char* const hb = halo + hh * C2_HALF;
+            const char* const ws = wlds + ((t + ring) & 3) * CH_WSLOT;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                bfr[nt][0] = *(const bf16x8*)(ws + boff0 + nt * 2048);
+                bfr[nt][1] = *(const bf16x8*)(ws + boff1 + nt * 2048);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                int hp;
+                if constexpr (UP) hp = (((wr * 2 + (mt >> 1) + dy - 1) >> 1) + 1) * (CH_TW / 2 + 2) + (((mt & 1) * 16 + lr + dx - 1) >> 1) + 1;
+                else hp = hp0 + ((mt >> 1) + dy) * CH_HW + (mt & 1) * 16 + dx;
+                const int ab = hp * 128 + (((hp & 7) ^ g) << 4);
+                af[mt][0] = *(const bf16x8*)(hb + ab);
+                af[mt][1] = *(const bf16x8*)(hb + (ab ^ 64));
+            }
+            if (lead) {
+                const int t2 = t + 2 < CH_NKT ? t + 2 : t + 2 - CH_NKT;           // phases 16, 17: the next tile's W(0), W(1) (the weights do not depend on the tile)
+                stage_w(t2, (t + 2 + ring) & 3);                                  // slot read in phase t-2: both groups are past it
+                if (lazy && t == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // W(1) is older than the previous tile's 16 stores: they may stay in flight
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // W(t+1) landed
+            } else {
+                if (t == 9 && nxt < NT) fill_half(nxt, 0);                        // half A is free: every wave has drained its phase-8 reads
+                if (t == 7 || t == 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // half B of this tile / half A of the next, issued >= 7 phases ago
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+        }
+        HSTAMP(2)
+        if (lead) asm volatile("s_barrier" ::: "memory");                        // re-align: both groups run the epilogue together
+        HSTAMP(3)
+        if constexpr (fast) {
+            f32x4 bias[4], rres[4][4];
+            const long trow0 = __builtin_amdgcn_readfirstlane((int)(((long)b * H + y0) * Wd + x0 >> 31)) * (1L << 31) + __builtin_amdgcn_readfirstlane((int)((((long)b * H + y0) * Wd + x0) & 0x7fffffff));
+            int lrow = wr * 2 * Wd + lr;
+            asm volatile("" : "+v"(lrow));
+            halo_epi_loads<RES>(ep, trow0, lrow, Wd, wc, g, rres);
+            if constexpr (RES != 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+            halo_bias_read(lds_bias, wc, g, bias);
+            halo_epi_stores<RES, OF32>(ep, acc, bias, rres, trow0, lrow, Wd, tix, gn_part, red, tid, w, wc, g, lr);
+            lazy = true;
+        } else halo_epilogue(ep, acc, mrow, Wd, tix, vec, gn_part, red, tid, w, wc, g, lr);
+        HSTAMP(4)
+        ++pit;
+        if (!lead && nxt < NT) fill_half(nxt, 1);                                 // half B is free since phase 17; needed in phase 9 of the next tile
+        tix = nxt;
+        ring ^= 2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // Takes 3x3 / pad 1 / stride 1 convolutions with Cin = Cout = 128 on images whose sides are multiples of the
 // 8 x 32 tile; returns false otherwise (the implicit-GEMM kernels handle the rest).
@@ -249,17 +582,52 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
     if (tiles < 128) return false;
     Epi<bf16> ep{e, M, N};
     const dim3 grid(tiles < 256 ? tiles : 256), block(512);
-#define CH_LAUNCH(STAG, UP)                                                                                                  \
+    // fast epilogue (round 6): vector layout, per-channel bias, no per-row bias / activation, and one of the residual / output combinations instantiated below
+    int epk = -1;
+    {
+        const long ldr = e.ldr ? e.ldr : e.ldc;
+        const bool vec_host = ((e.ldc | ldr) & 3) == 0 && (N & 3) == 0 && e.ldc < (1 << 20) && ldr < (1 << 20);
+        const int res = !e.residual ? 0 : e.res_f32 ? 1 : 2;
+        if (vec_host && e.bias_n && !e.bias_m && e.act == 0 && pg_tune->conv_halo != 5) {
+            const int k = res * 2 + (e.out_f32 ? 1 : 0);
+            if (k == 0 || k == 1 || k == 3 || k == 4) epk = k;          // none->bf16, none->fp32, fp32->fp32 (the decoder's three), bf16->bf16
+            if (a.up && res) epk = -1;
+        }
+    }
+    const int mode = pg_tune->conv_halo;
+#define CH_GO(...)                                                                                                            \
     {                                                                                                                         \
-        auto kfn = conv3x3_halo_kernel<Epi<bf16>, STAG, UP>;                                                                  \
-        (void)PG_DYN_LDS(kfn, CH_LDS); \
+        auto kfn = __VA_ARGS__;                                                                                               \
+        (void)PG_DYN_LDS(kfn, CH_LDS);                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, H, Wd, gn_part);  \
     }
-    if (gn_part && (e.ldc & 3) != 0) gn_part = nullptr;
-    if (gn_nsplit) *gn_nsplit = gn_part ? (H / CH_TH) * (Wd / CH_TW) : 0;
-    if (pg_tune->conv_halo == 2) { if (a.up) CH_LAUNCH(false, true) else CH_LAUNCH(false, false) }
-    else { if (a.up) CH_LAUNCH(true, true) else CH_LAUNCH(true, false) }
-#undef CH_LAUNCH
+#define CH_EPK(STAG, UP, PROF, PD)                                                                                            \
+    switch (epk) {                                                                                                            \
+        case 0: CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, UP, PROF, PD, 0>) break;                                            \
+        case 1: CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, UP, PROF, PD, 1>) break;                                            \
+        case 3: if constexpr (!UP) { CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, false, PROF, PD, 3>) } break;                  \
+        case 4: if constexpr (!UP) { CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, false, PROF, PD, 4>) } break;                  \
+        default: CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, UP, PROF, PD, -1>) break;                                          \
+    }
+#define C2_EPK(UP, PROF)                                                                                                      \
+    switch (epk) {                                                                                                            \
+        case 0: CH_GO(conv3x3_halo2_kernel<Epi<bf16>, UP, PROF, 0>) break;                                                     \
+        case 1: CH_GO(conv3x3_halo2_kernel<Epi<bf16>, UP, PROF, 1>) break;                                                     \
+        case 3: if constexpr (!UP) { CH_GO(conv3x3_halo2_kernel<Epi<bf16>, false, PROF, 3>) } break;                           \
+        case 4: if constexpr (!UP) { CH_GO(conv3x3_halo2_kernel<Epi<bf16>, false, PROF, 4>) } break;                           \
+        default: CH_GO(conv3x3_halo2_kernel<Epi<bf16>, UP, PROF, -1>) break;                                                   \
+    }
+    if (mode == 13) { C2_EPK(false, true) }
+    else if (mode == 3) { if (a.up) { C2_EPK(true, false) } else { C2_EPK(false, false) } }
+    else if (mode == 2) { if (a.up) CH_GO(conv3x3_halo_kernel<Epi<bf16>, false, true>) else CH_GO(conv3x3_halo_kernel<Epi<bf16>, false, false>) }
+    else if (mode == 11) { CH_EPK(true, false, true, 2) }
+    else if (mode == 12) { CH_EPK(true, false, true, 3) }
+    else if (mode == 14) { CH_GO(conv3x3_halo_kernel<Epi<bf16>, true, false, true, 2, 0, 1>) }      // TEMP
+    else if (mode == 4) { if (a.up) { CH_EPK(true, true, false, 3) } else { CH_EPK(true, false, false, 3) } }
+    else { if (a.up) { CH_EPK(true, true, false, 2) } else { CH_EPK(true, false, false, 2) } }
+#undef CH_EPK
+#undef C2_EPK
+#undef CH_GO
     return true;
 }
 

@@ -10,6 +10,8 @@ it = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 cfg = PlanGenConfig.janus_pro_1b()
 e = Engine(cfg, dtype="bf16", max_rows=2, max_prompt=16, max_new=8, max_images=B, with_vq_encoder=True)
 e.init_synthetic(seed=0)
+for kv in os.environ.get("PG_OPTS", "").split(","):          # e.g. PG_OPTS=conv_halo=3
+    if kv: e.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 codes = torch.randint(0, cfg.img_vocab, (B, cfg.img_tokens)).int()
 for i in range(it):
     torch.cuda.synchronize(); t0 = time.perf_counter()
