@@ -835,8 +835,3 @@ extern "C" int pg_bench_mfma_peak(int mode, int waves_per_simd, int constant, in
     return rc;
 }
 
-// TEMP
-bool halo_prof_read(unsigned long long* dst);
-extern "C" int pg_bench_halo_prof(unsigned long long* out) { return halo_prof_read(out) ? 0 : 1; }
-bool halo_prof2_read(unsigned long long* dst);
-extern "C" int pg_bench_halo_prof2(unsigned long long* out) { return halo_prof2_read(out) ? 0 : 1; }

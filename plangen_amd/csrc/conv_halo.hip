@@ -3,17 +3,18 @@
 // decoder's time on the im2col-per-K-tile GEMM kernel).
 //
 // Direct convolution with an LDS-resident INPUT HALO TILE: a block owns 8 x 32 output pixels x all 128 output
-// channels.  The (8+2) x (32+2) x 128-channel input patch (85 KiB) is brought into LDS ONCE with
+// channels.  The (8+2) x (32+2) x 128-channel input patch (85 KiB, 90 KiB as laid out) is brought into LDS ONCE with
 // global_load_lds (out-of-image pixels come from a zero page) and serves all 9 taps x 128 channels = 18 K
 // tiles of 64: the A operand is never re-fetched per tap, only the weights stream (16 KiB per K tile, a
-// 4-slot LDS ring three tiles ahead, counted vmcnt, one barrier per K tile).
+// 4-slot LDS ring, counted vmcnt, the two wave groups one barrier apart).
 //
 //   waves: 8 = 4 (pixel rows pairs) x 2 (64 output channels); a wave owns 2 rows x 32 px = 4 MFMA m-tiles of
 //          16 consecutive pixels, and 4 n-tiles: acc 4x4 f32x4, 32 MFMAs (16x16x32 bf16) per K tile.
-//   halo LDS layout: [halo pixel hp][16 chunks of 16 B], chunk position XOR (hp & 15) -- applied through the
-//          SOURCE address of the LDS-DMA (the DMA writes lane-linear).  A fragment read of 16 consecutive
-//          pixels x 4 k-groups then touches 16 distinct 16-byte slots per lane group (pixel stride 256 B would
-//          otherwise be a 16-way conflict).  The four k-steps of a tap are address ^ {0, 64, 128, 192}.
+//   halo LDS layout (round 6): [patch row][36 pixels][16 chunks of 16 B] -- the 34 halo pixels of a row padded to nine 4-pixel LDS-DMA instructions, so an
+//          instruction's row and segment are wave-uniform -- with the chunk position XORed with 2 * (pixel-in-row & 7) through the SOURCE address of the
+//          LDS-DMA (the DMA writes lane-linear).  A ds_read_b128 lane group is 8 pixels of one k-group and 8 of the next: with this map the 16 lanes
+//          touch 16 distinct 16-byte slots for EVERY first-pixel alignment (XOR (pixel & 15), rounds 2-5, collided 2-way on every dx = 1 tap).
+//          The four k-steps of a tap are address ^ {0, 64, 128, 192}.  90 KiB.
 //   weights: [Cout][tap][Cin] (K = tap*128 + ci, the engine's conv layout); LDS rows of 128 B with the
 //          (row>>1)&7 XOR swizzle of the GEMM kernels.
 //   operands swapped in the MFMA (D = W . A^T): a lane holds 4 consecutive output channels of one pixel ->
@@ -23,6 +24,14 @@
 //          H x W is the OUTPUT size, the input is H/2 x W/2, the halo patch is the 6 x 18 SOURCE pixels an
 //          8 x 32 output tile touches, and output pixel (py, px), tap (dy, dx) reads source halo pixel
 //          (((py+dy-1)>>1)+1, ((px+dx-1)>>1)+1); zero padding of the upsampled image == zero padding of the source.
+//
+// Round 6, per-tile stamps (s_memrealtime, block 7, 64 x 384^2, profiles/r06_c_vq_decode.md): a tile was 20.2 us = top wait 1.5 + 18 K tiles
+// 12.4 + epilogue 6.0-7.2, against 7.7 us of MFMA at full rate.  What was kept: the epilogue without a wait behind its first store (below), the padded patch rows
+// (scalar row / segment decode), the conflict-free chunk map, W(t+2) staged first in its phase: 3x3 kernels -10 %, VQ decode -2.0 ms on one box.  What was built,
+// measured and removed (commit 2af565a has it): the patch as two CHANNEL halves filled ping-pong under the other half's nine K tiles, wave roles split (weights /
+// halo) -- top wait + epilogue 7.5 -> 2.3 us but the K loop 12.4 -> 15.7 us, the decode 1.4 ms slower; prefetch distance 3 on the weight ring (neutral); half the
+// weight stream (K loop 12.47 -> 12.14 us: the loop is not ingest-bound); stores allowed to stay in flight across the tile boundary (neutral).  A phase is
+// [16 fragment reads: 0.2 us of LDS time] beside [the other wave group's 32 MFMAs: 0.25-0.3 us], strictly alternating: ~10 us per tile is the schedule's own bound.
 #include "gemm_common.h"
 
 #define CH_TH 8
@@ -31,18 +40,12 @@
 #define CH_HP ((CH_TH + 2) * CH_HW)             // 340 halo pixels
 #define CH_HALO_BYTES (88 * 1024)               // 88 wave-instructions x 1 KiB (>= 340 x 256 B)
 #define CH_WSLOT 16384                          // one K tile of weights: 128 rows x 128 B
-#define CH_RED (CH_HALO_BYTES + 4 * CH_WSLOT)       // 1 KiB: per-wave GroupNorm partials of the epilogue
+#define CH_HWP 36                               // round 6: halo rows padded to 9 LDS-DMA instructions of 4 pixels (the 3x3 kernel's own patch: 10 x 36 pixels = 90 KiB)
+#define CH_PATCH_BYTES (90 * 1024)
+#define CH_RED (CH_PATCH_BYTES + 4 * CH_WSLOT)      // 1 KiB: per-wave GroupNorm partials of the epilogue
 #define CH_BIAS (CH_RED + 1024)                 // 512 B: the 128 per-channel biases (fast epilogue), staged once per block
 #define CH_LDS (CH_BIAS + 512)
 #define CH_NKT 18                               // 9 taps x (128 / 64)
-
-// TEMP instrumentation
-__device__ unsigned long long g_halo_prof[2 * 64 * 8];
-bool halo_prof_read(unsigned long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_prof), sizeof(g_halo_prof)) == hipSuccess; }
-__device__ unsigned long long g_halo_prof2[2 * 18 * 8];
-bool halo_prof2_read(unsigned long long* dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_prof2), sizeof(g_halo_prof2)) == hipSuccess; }
-#define PSTAMP(t, k) if constexpr (PROF) { if (blockIdx.x == 7 && (w & 3) == 0 && l == 0 && pit == 20) g_halo_prof2[((w >> 2) * 18 + (t)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); }
-#define HSTAMP(k) if constexpr (PROF) { if (blockIdx.x == 7 && (w & 3) == 0 && l == 0 && pit < 64) g_halo_prof[((w >> 2) * 64 + pit) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); }
 
 // Epilogue of one 8 x 32 tile, shared by the two halo kernels: a wave's 4 x 4 f32x4 accumulators (m-tile mt = pixel row pair / 16-pixel half, n-tile nt = 16
 // output channels) through the shared Epi in two batches of 8 fragments; with gn_part the GroupNorm(32 groups of 4 channels) partial sums of the STORED values.
@@ -200,13 +203,13 @@ __device__ __forceinline__ void halo_bias_read(const float* lds_bias, int wc, in
     for (int nt = 0; nt < 4; ++nt) bias[nt] = *(const f32x4*)(lds_bias + wc * 64 + nt * 16 + g * 4);
 }
 
-template <class EP, bool STAG, bool UP, bool PROF = false, int PD = 2, int EPK = -1, int WI = 2>     // WI = 1: TEMP experiment, half the weight stream (wrong results)      // EPK: -1 generic epilogue; else residual kind (0 none, 1 fp32, 2 bf16) * 2 + (fp32 output)
+template <class EP, bool STAG, bool UP, int EPK = -1>      // EPK: -1 generic epilogue; else residual kind (0 none, 1 fp32, 2 bf16) * 2 + (fp32 output)
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt,
                                                           const bf16* __restrict__ zeros, EP ep, int B, int H, int Wd,
                                                           float* __restrict__ gn_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem;
-    char* const wlds = smem + CH_HALO_BYTES;
+    char* const wlds = smem + CH_PATCH_BYTES;
     float* const red = (float*)(smem + CH_RED);
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,51 +231,52 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
         const int tt = t < CH_NKT ? t : CH_NKT - 1;                            // clamped tail: keeps the counts exact
         char* d = wlds + (t & 3) * CH_WSLOT + w * 1024;
         glds16(wsrc0 + tt * 64, d);
-        if constexpr (WI == 2) glds16(wsrc1 + tt * 64, d + 8192);
+        glds16(wsrc1 + tt * 64, d + 8192);
     };
     // B (weight) fragment addresses inside a slot
     const int swz = (lr >> 1) & 7;
     const int boff0 = (wc * 64 + lr) * 128 + ((g ^ swz) << 4), boff1 = boff0 ^ 64;
-    // A fragment: halo pixel of (m-tile mt, tap) = hp0 + (mt>>1)*34 + (mt&1)*16 + dy*34 + dx
-    const int hp0 = (wr * 2) * CH_HW + lr;
 
     f32x4 acc[4][4];
     bf16x8 af[4][2], bfr[4][2];
 
     int b = 0, y0 = 0, x0 = 0;
-    // halo fill (11 LDS-DMA instructions per wave, 4 halo pixels x 16 chunks each) + the first three weight tiles
+    // halo fill (12 LDS-DMA instructions per wave, 4 halo pixels x 16 chunks each) + the first weight tiles
     auto fill = [&](int tix) __attribute__((always_inline)) {
         b = tix / tiles_img;
         const int r = tix - b * tiles_img;
         y0 = (r / tiles_x) * CH_TH; x0 = (r % tiles_x) * CH_TW;
-        constexpr int HWD = UP ? CH_TW / 2 + 2 : CH_HW, NHP = UP ? (CH_TH / 2 + 2) * HWD : CH_HP, NJ = UP ? 4 : 11;
+        // Round 6: a halo row is padded to a whole number of 4-pixel LDS-DMA instructions (36 / 20 pixels for 34 / 18), so an instruction's row and segment
+        // are wave-uniform (scalar unit) and a lane only adds its pixel-in-segment: ~8 vector instructions per DMA instead of ~35 (division by 34, 64-bit
+        // multiply-adds, an exec-masked branch).
+        constexpr int HW = UP ? CH_TW / 2 + 2 : CH_HW, SPR = UP ? 5 : 9, NROW = UP ? CH_TH / 2 + 2 : CH_TH + 2, NQ = NROW * SPR, NJ = (NQ + 7) / 8;
         const int Hs = UP ? H / 2 : H, Ws = UP ? Wd / 2 : Wd;                    // source image
         const int sy0 = (UP ? y0 / 2 : y0) - 1, sx0 = (UP ? x0 / 2 : x0) - 1;      // source coords of halo pixel (0, 0)
         const bf16* img = X + (long)b * Hs * Ws * 128;
         int ll = l;
-        asm volatile("" : "+v"(ll));                                           // per-lane halo coordinates are recomputed per tile, not kept in 20+ registers through the MFMA loop
+        asm volatile("" : "+v"(ll));                                           // the per-lane parts are recomputed per tile (a handful of instructions), not held in registers through the MFMA loop
+        const int lp = ll >> 4, pos = ll & 15;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int q = j * 8 + w;                                           // wave-instruction index, 1 KiB each
-            int hp = q * 4 + (ll >> 4);
-            const int pos = ll & 15;
-            const bool inr = hp < NHP;
-            hp = inr ? hp : NHP - 1;
-            const int hy = hp / HWD, hx = hp - hy * HWD;
-            const int y = sy0 + hy, x = sx0 + hx;
-            const bool ok = inr && y >= 0 && y < Hs && x >= 0 && x < Ws;
-            const int sch = pos ^ (hp & 15);
-            const bf16* src = ok ? img + ((long)y * Ws + x) * 128 + sch * 8 : zeros + sch * 8;
-            glds16(src, halo + q * 1024);
+            int q = j * 8 + w;                                                 // wave-instruction index, 1 KiB = 4 halo pixels x 16 chunks
+            q = q < NQ ? q : NQ - 1;                                           // surplus instructions repeat the last one (same bytes to the same place)
+            const int hy = q / SPR, seg = q - hy * SPR;                        // scalar
+            const int y = sy0 + hy;
+            const bool yok = y >= 0 && y < Hs;
+            const int hx = seg * 4 + lp;
+            const bool ok = yok && hx < HW && (unsigned)(sx0 + hx) < (unsigned)Ws;
+            const unsigned sch16 = (unsigned)((pos ^ ((hx & 7) << 1)) << 4);      // chunk position XOR 2*(hx & 7): see the fragment read
+            const char* const rowp = (const char*)(img + ((long)y * Ws + sx0) * 128);      // scalar; not dereferenced when the row is outside the image
+            const char* const base = ok ? rowp : (const char*)zeros;
+            const unsigned off = ok ? (unsigned)(hx << 8) + sch16 : sch16;
+            glds16(base + off, halo + q * 1024);
         }
         stage_w(0); stage_w(1);
-        if (!STAG || PD == 3) stage_w(2);
+        if (!STAG) stage_w(2);
     };
-    int tix = blockIdx.x; int pit = 0;
-    bool lazy = false;                                              // fast epilogue of the PREVIOUS tile: 16 stores sit between W(PD-1) and W(PD) in this wave's queue
+    int tix = blockIdx.x;
     if (tix < NT) fill(tix);
     while (tix < NT) {
-        HSTAMP(0)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -286,24 +290,24 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
             // Round 3: the halo and W(0) are retired here and read by the first wave group right behind the barrier -- the same-phase
             // form the staging rule forbids (tools/dma_isa_check.py) -- so a second barrier separates retirement from the first read
             // (once per 8x32 tile; both groups pass it, the barrier counts stay equal).
-            // Round 6: W(1..PD-1) may fly, and so may the previous tile's 16 epilogue stores (issued BEHIND the fill: waiting for them here was 1.5 us per tile)
-            if (lazy) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WI * (PD - 1) + 16) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WI * (PD - 1)) : "memory");
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
             asm volatile("s_barrier" ::: "memory");
             if (wr >= 2) asm volatile("s_barrier" ::: "memory");
         }
-        HSTAMP(1)
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
             int abase[4];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                int hp;
-                if constexpr (UP) hp = (((wr * 2 + (mt >> 1) + dy - 1) >> 1) + 1) * (CH_TW / 2 + 2) + (((mt & 1) * 16 + lr + dx - 1) >> 1) + 1;
-                else hp = hp0 + ((mt >> 1) + dy) * CH_HW + (mt & 1) * 16 + dx;
-                abase[mt] = hp * 256 + (((hp & 15) ^ g) << 4);
+                int hrow, hx;                                               // patch row and pixel-in-row; LDS pixel slot = row * (padded width) + hx, chunk XOR (hx & 15)
+                if constexpr (UP) { hrow = ((wr * 2 + (mt >> 1) + dy - 1) >> 1) + 1; hx = (((mt & 1) * 16 + lr + dx - 1) >> 1) + 1; }
+                else { hrow = wr * 2 + (mt >> 1) + dy; hx = (mt & 1) * 16 + dx + lr; }
+                // chunk position XOR 2*(hx & 7): a ds_read_b128 lane group is 8 pixels of one k-group + 8 of the next (MI355X_MICROARCH.md LDS table), and XOR (hx & 15)
+                // collided 2-way whenever the first pixel was odd (every dx = 1 tap: a third of the A reads at twice the LDS cycles); this map is conflict-free for
+                // every pixel alignment and k-step (exhaustive check over the four lane groups).
+                abase[mt] = (hrow * (UP ? 20 : CH_HWP) + hx) * 256 + ((((hx & 7) << 1) ^ g) << 4);
             }
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) {
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
                     asm volatile("s_barrier" ::: "memory");                    // round 3: retirement and first read one barrier apart (staging rule, strict form)
                     stage_w(t + 3);                                            // slot of tile t-1: every wave is past its reads
                 }
-                PSTAMP(t, 0)
+                if constexpr (STAG) stage_w(t + 2);                           // round 6: first thing in the phase (it was behind the 16 fragment reads): W(t+2) gets ~0.2 us more to land before phase t+1 waits for it
                 const char* ws = wlds + (t & 3) * CH_WSLOT;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
@@ -328,21 +332,11 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
                     af[mt][1] = *(const bf16x8*)(halo + (abase[mt] ^ ((kh * 2 + 1) << 6)));
                 }
                 if constexpr (STAG) {
-                    // W(t+PD) goes into the slot read in phase t+PD-4: PD = 2 two phases back; PD = 3 the PREVIOUS phase's slot, which the trailing group read one
-                    // barrier ago -- so with PD = 3 every wave drains its fragment reads (lgkmcnt(0)) in FRONT of the barrier (the gemm256 rule).
-                    PSTAMP(t, 1)
-                    stage_w(t + PD);
-                    // W(t+1) landed.  In the first PD-1 phases of a tile it is OLDER than the previous tile's 16 stores, which may therefore stay in flight.
-                    if (lazy && t <= PD - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WI * (PD - 1) + 16) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WI * (PD - 1)) : "memory");
-                    PSTAMP(t, 2)
-                    if constexpr (PD == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // W(t+1) landed
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_barrier" ::: "memory");
                 }
-                PSTAMP(t, 3)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                PSTAMP(t, 4)
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -354,12 +348,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                PSTAMP(t, 5)
                 if constexpr (STAG) asm volatile("s_barrier" ::: "memory");
-                PSTAMP(t, 6)
             }
         }
-        HSTAMP(2)
         if (STAG && wr < 2) asm volatile("s_barrier" ::: "memory");
         // every wave must be done with the halo before the next tile's fill overwrites it; the fill (and the
         // first weight tiles) then go out BEFORE this tile's stores so they fly during the epilogue
@@ -367,7 +358,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
         const long mrow = ((long)b * H + y0 + wr * 2) * Wd + x0 + lr;
         const int tile_id = tix;                                        // (image, tile) index of THIS tile
         tix += G;
-        HSTAMP(3)
         if constexpr (fast) {
             const long trow0 = __builtin_amdgcn_readfirstlane((int)(((long)b * H + y0) * Wd + x0 >> 31)) * (1L << 31) + __builtin_amdgcn_readfirstlane((int)((((long)b * H + y0) * Wd + x0) & 0x7fffffff));
             int lrow = wr * 2 * Wd + lr;
@@ -381,193 +371,14 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
             if constexpr (RES != 0) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) the compiler can see on EVERY path: otherwise it guards the MFMA loop's first register write with its own (and waits there for the stores)
             halo_bias_read(lds_bias, wc, g, bias);
             halo_epi_stores<RES, OF32>(ep, acc, bias, rres, trow0, lrow, Wd, tile_id, gn_part, red, tid, w, wc, g, lr);
-            lazy = true;
         } else {
             if (tix < NT) fill(tix);
             halo_epilogue(ep, acc, mrow, Wd, tile_id, vec, gn_part, red, tid, w, wc, g, lr);
         }
-        HSTAMP(4)
-        ++pit;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-
-// ------------------------------------------------------------------------------- round 6: the halo as two CHANNEL halves, ping-pong
-// conv3x3_halo_kernel serialises, per 8 x 32 tile and CU, [halo fill + epilogue stores drain] -> [18 K tiles of MFMA]: with one 85 KiB patch per CU there is
-// nowhere to receive the next tile's patch while this tile's MFMAs read the current one (19.7 us per tile at 384^2, 7.7 us of it MFMA at full rate).  A second
-// SPATIAL patch does not fit (2 x 85 KiB + the weight ring > 160 KiB) and halving the tile doubles the weight stream.  Splitting the patch by INPUT CHANNEL does fit:
-//   half A = channels 0..63 of the (8+2) x (32+2) patch, half B = channels 64..127: 2 x 42.5 KiB = the same 85 KiB.
-//   K order (half, tap, 64 channels) instead of (tap, 128 channels): phases 0..8 read only half A, phases 9..17 only half B.
-//   => half A of tile i+1 is filled while phases 9..17 of tile i run (issued in phase 9, needed after the epilogue), half B of tile i+1 while the epilogue of tile i and
-//      phases 0..8 of tile i+1 run (issued behind the epilogue, needed in phase 9): no halo byte is waited for within ~4 us of its issue.
-// VMEM operations retire in issue order, so a wave that streams weights with counted waits (one K tile every ~0.5 us) cannot also carry a halo fill that should
-// fly for microseconds.  The two wave groups of the staggered schedule therefore split the ROLES: the leading group (waves 0..3) stages the whole weight tile
-// (4 LDS-DMA instructions per wave per phase, s_waitcnt vmcnt(4)), the trailing group (waves 4..7) issues the halo halves (11 instructions per wave per half) and waits
-// for them with vmcnt(0) seven phases later (phase 16 for half A, phase 7 for half B) -- its queue holds nothing else but its own epilogue's accesses.
-// Barriers per tile: leading 18 x 2 + 1 (re-align at the end), trailing 1 (start, one barrier behind) + 18 x 2.  Every staged piece is retired (vmcnt + barrier) at
-// least two barriers before its first read, every slot re-staged at least two barriers after its last read (tools/dma_isa_check.py, kind halo_pp).
-//   half layout: [halo pixel hp][8 chunks of 16 B], chunk position XOR (hp & 7) through the DMA's source address: a ds_read_b128 lane group (16 pixels, two
-//   k-groups -- MI355X_MICROARCH.md LDS table) touches 16 distinct 16-byte slots for every pixel alignment (the 256-byte layout of the kernel above pays 2 x for odd dx).
-// The accumulation order differs from the im2col kernels' (same products, other order of the 36 partial sums per output): equal to the kernel above to fp32
-// re-association, bit-identical to it when one channel half of the input is zero (tests/test_gpu_ops.py).
-#define C2_HALF (44 * 1024)
-
-template <class EP, bool UP, bool PROF = false, int EPK = -1>
-__global__ __launch_bounds__(512) void conv3x3_halo2_kernel(const bf16* __restrict__ X, const bf16* __restrict__ Wt, const bf16* __restrict__ zeros, EP ep, int B,
-                                                           int H, int Wd, float* __restrict__ gn_part) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const halo = smem;
-    char* const wlds = smem + CH_HALO_BYTES;
-    float* const red = (float*)(smem + CH_RED);
-    const int tid = threadIdx.x, l = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1, g = l >> 4, lr = l & 15;
-    const bool lead = w < 4;
-    const int tiles_x = Wd / CH_TW, tiles_y = H / CH_TH, tiles_img = tiles_x * tiles_y;
-    const int NT = tiles_img * B, G = gridDim.x;
-    const bool vec = ep.vec_ok(0, 0);
-    constexpr bool fast = EPK >= 0;
-    constexpr int RES = EPK >= 0 ? EPK / 2 : 0; constexpr bool OF32 = EPK >= 0 && (EPK & 1);
-    float* const lds_bias = (float*)(smem + CH_BIAS);
-    halo_bias_stage(ep, fast, tid, lds_bias);
-    bool lazy = false;
-
-    // weights (leading group): wave w, instruction i covers LDS rows ((i*4 + w)*8 .. +7) of the 128-row tile; K tile tt = half*9 + tap
-    const int wsrow = (w & 3) * 8 + (l >> 3);
-    const int wsc = ((l & 7) ^ (((w & 1) << 2) + (l >> 4))) * 8;
-    const bf16* const wsrc = Wt + (long)wsrow * (9 * 128) + wsc;
-    auto stage_w = [&](int tt, int slot) __attribute__((always_inline)) {
-        const int hh = tt >= 9 ? 1 : 0;
-        const bf16* src = wsrc + (tt - 9 * hh) * 128 + hh * 64;
-        char* d = wlds + slot * CH_WSLOT + (w & 3) * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(src + (long)i * 32 * (9 * 128), d + i * 4096);
-    };
-    // halo half hh of tile tx (trailing group): wave-instruction q = 8 halo pixels x 8 chunks
-    auto fill_half = [&](int tx, int hh) __attribute__((always_inline)) {
-        const int fb = tx / tiles_img;
-        const int r = tx - fb * tiles_img;
-        const int fy0 = (r / tiles_x) * CH_TH, fx0 = (r % tiles_x) * CH_TW;
-        constexpr int HWD = UP ? CH_TW / 2 + 2 : CH_HW, NHP = UP ? (CH_TH / 2 + 2) * HWD : CH_HP, NJ = UP ? 4 : 11, NQ = (NHP + 7) / 8;
-        const int Hs = UP ? H / 2 : H, Ws = UP ? Wd / 2 : Wd;
-        const int sy0 = (UP ? fy0 / 2 : fy0) - 1, sx0 = (UP ? fx0 / 2 : fx0) - 1;
-        const bf16* img = X + (long)fb * Hs * Ws * 128 + hh * 64;
-        char* const dst = halo + hh * C2_HALF;
-        int ll = l;
-        asm volatile("" : "+v"(ll));                                           // recomputed per fill, not held through the MFMA loop
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            int q = j * 4 + (w & 3);
-            q = q < NQ ? q : NQ - 1;                                            // surplus instructions repeat the last one (same bytes to the same place)
-            int hp = q * 8 + (ll >> 3);
-            const int pos = ll & 7;
-            const bool inr = hp < NHP;
-            hp = inr ? hp : NHP - 1;
-            const int hy = hp / HWD, hx = hp - hy * HWD;
-            const int y = sy0 + hy, x = sx0 + hx;
-            const bool ok = inr && y >= 0 && y < Hs && x >= 0 && x < Ws;
-            const int sch = pos ^ (hp & 7);
-            const bf16* src = ok ? img + ((long)y * Ws + x) * 128 + sch * 8 : zeros + sch * 8;
-            glds16(src, dst + q * 1024);
-        }
-    };
-    const int swz = (lr >> 1) & 7;
-    const int boff0 = (wc * 64 + lr) * 128 + ((g ^ swz) << 4), boff1 = boff0 ^ 64;
-    const int hp0 = (wr * 2) * CH_HW + lr;
-
-    f32x4 acc[4][4];
-    bf16x8 af[4][2], bfr[4][2];
-
-    int tix = blockIdx.x, ring = 0, pit = 0;
-    if (tix < NT) {
-        if (lead) { stage_w(0, 0); stage_w(1, 1); }
-        else { fill_half(tix, 0); fill_half(tix, 1); }
-    }
-    if (lead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   // W(0); W(1) is retired by phase 0's wait
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // both halves of the first tile
-    asm volatile("s_barrier" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    while (tix < NT) {
-        const int b = tix / tiles_img;
-        const int rr = tix - b * tiles_img;
-        const int y0 = (rr / tiles_x) * CH_TH, x0 = (rr % tiles_x) * CH_TW;
-        const long mrow = ((long)b * H + y0 + wr * 2) * Wd + x0 + lr;
-        const int nxt = tix + G;
-        HSTAMP(0)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!lead) asm volatile("s_barrier" ::: "memory");                       // trailing group: one barrier behind for the whole tile
-        HSTAMP(1)
-#pragma unroll 1
-        for (int t = 0; t < CH_NKT; ++t) {
-            const int hh = t >= 9 ? 1 : 0, tap = t - 9 * hh;
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const char* const hb = halo + hh * C2_HALF;
-            const char* const ws = wlds + ((t + ring) & 3) * CH_WSLOT;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                bfr[nt][0] = *(const bf16x8*)(ws + boff0 + nt * 2048);
-                bfr[nt][1] = *(const bf16x8*)(ws + boff1 + nt * 2048);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                int hp;
-                if constexpr (UP) hp = (((wr * 2 + (mt >> 1) + dy - 1) >> 1) + 1) * (CH_TW / 2 + 2) + (((mt & 1) * 16 + lr + dx - 1) >> 1) + 1;
-                else hp = hp0 + ((mt >> 1) + dy) * CH_HW + (mt & 1) * 16 + dx;
-                const int ab = hp * 128 + (((hp & 7) ^ g) << 4);
-                af[mt][0] = *(const bf16x8*)(hb + ab);
-                af[mt][1] = *(const bf16x8*)(hb + (ab ^ 64));
-            }
-            if (lead) {
-                const int t2 = t + 2 < CH_NKT ? t + 2 : t + 2 - CH_NKT;           // phases 16, 17: the next tile's W(0), W(1) (the weights do not depend on the tile)
-                stage_w(t2, (t + 2 + ring) & 3);                                  // slot read in phase t-2: both groups are past it
-                if (lazy && t == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // W(1) is older than the previous tile's 16 stores: they may stay in flight
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // W(t+1) landed
-            } else {
-                if (t == 9 && nxt < NT) fill_half(nxt, 0);                        // half A is free: every wave has drained its phase-8 reads
-                if (t == 7 || t == 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // half B of this tile / half A of the next, issued >= 7 phases ago
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_barrier" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[mt][nt], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_barrier" ::: "memory");
-        }
-        HSTAMP(2)
-        if (lead) asm volatile("s_barrier" ::: "memory");                        // re-align: both groups run the epilogue together
-        HSTAMP(3)
-        if constexpr (fast) {
-            f32x4 bias[4], rres[4][4];
-            const long trow0 = __builtin_amdgcn_readfirstlane((int)(((long)b * H + y0) * Wd + x0 >> 31)) * (1L << 31) + __builtin_amdgcn_readfirstlane((int)((((long)b * H + y0) * Wd + x0) & 0x7fffffff));
-            int lrow = wr * 2 * Wd + lr;
-            asm volatile("" : "+v"(lrow));
-            halo_epi_loads<RES>(ep, trow0, lrow, Wd, wc, g, rres);
-            if constexpr (RES != 0) __builtin_amdgcn_s_waitcnt(0x0F70);
-            halo_bias_read(lds_bias, wc, g, bias);
-            halo_epi_stores<RES, OF32>(ep, acc, bias, rres, trow0, lrow, Wd, tix, gn_part, red, tid, w, wc, g, lr);
-            lazy = true;
-        } else halo_epilogue(ep, acc, mrow, Wd, tix, vec, gn_part, red, tid, w, wc, g, lr);
-        HSTAMP(4)
-        ++pit;
-        if (!lead && nxt < NT) fill_half(nxt, 1);                                 // half B is free since phase 17; needed in phase 9 of the next tile
-        tix = nxt;
-        ring ^= 2;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
 
 // Takes 3x3 / pad 1 / stride 1 convolutions with Cin = Cout = 128 on images whose sides are multiples of the
 // 8 x 32 tile; returns false otherwise (the implicit-GEMM kernels handle the rest).
@@ -582,51 +393,38 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
     if (tiles < 128) return false;
     Epi<bf16> ep{e, M, N};
     const dim3 grid(tiles < 256 ? tiles : 256), block(512);
-    // fast epilogue (round 6): vector layout, per-channel bias, no per-row bias / activation, and one of the residual / output combinations instantiated below
+    if (gn_part && (e.ldc & 3) != 0) gn_part = nullptr;
+    if (gn_nsplit) *gn_nsplit = gn_part ? (H / CH_TH) * (Wd / CH_TW) : 0;
+    // fast epilogue (round 6): vector layout, per-channel bias, no per-row bias / activation, and one of the residual / output combinations instantiated below;
+    // anything else, and the lock-step variant (conv_halo = 2), keeps the generic one (same values: tests/test_gpu_full.py compares whole decodes)
     int epk = -1;
     {
         const long ldr = e.ldr ? e.ldr : e.ldc;
         const bool vec_host = ((e.ldc | ldr) & 3) == 0 && (N & 3) == 0 && e.ldc < (1 << 20) && ldr < (1 << 20);
         const int res = !e.residual ? 0 : e.res_f32 ? 1 : 2;
-        if (vec_host && e.bias_n && !e.bias_m && e.act == 0 && pg_tune->conv_halo != 5) {
+        if (vec_host && e.bias_n && !e.bias_m && e.act == 0) {
             const int k = res * 2 + (e.out_f32 ? 1 : 0);
             if (k == 0 || k == 1 || k == 3 || k == 4) epk = k;          // none->bf16, none->fp32, fp32->fp32 (the decoder's three), bf16->bf16
             if (a.up && res) epk = -1;
         }
     }
-    const int mode = pg_tune->conv_halo;
 #define CH_GO(...)                                                                                                            \
     {                                                                                                                         \
         auto kfn = __VA_ARGS__;                                                                                               \
         (void)PG_DYN_LDS(kfn, CH_LDS);                                                                                        \
         hipLaunchKernelGGL(kfn, grid, block, CH_LDS, s, (const bf16*)a.ptr, W, (const bf16*)a.zeros, ep, B, H, Wd, gn_part);  \
     }
-#define CH_EPK(STAG, UP, PROF, PD)                                                                                            \
+#define CH_EPK(UP)                                                                                                            \
     switch (epk) {                                                                                                            \
-        case 0: CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, UP, PROF, PD, 0>) break;                                            \
-        case 1: CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, UP, PROF, PD, 1>) break;                                            \
-        case 3: if constexpr (!UP) { CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, false, PROF, PD, 3>) } break;                  \
-        case 4: if constexpr (!UP) { CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, false, PROF, PD, 4>) } break;                  \
-        default: CH_GO(conv3x3_halo_kernel<Epi<bf16>, STAG, UP, PROF, PD, -1>) break;                                          \
+        case 0: CH_GO(conv3x3_halo_kernel<Epi<bf16>, true, UP, 0>) break;                                                      \
+        case 1: CH_GO(conv3x3_halo_kernel<Epi<bf16>, true, UP, 1>) break;                                                      \
+        case 3: if constexpr (!UP) { CH_GO(conv3x3_halo_kernel<Epi<bf16>, true, false, 3>) } break;                            \
+        case 4: if constexpr (!UP) { CH_GO(conv3x3_halo_kernel<Epi<bf16>, true, false, 4>) } break;                            \
+        default: CH_GO(conv3x3_halo_kernel<Epi<bf16>, true, UP, -1>) break;                                                    \
     }
-#define C2_EPK(UP, PROF)                                                                                                      \
-    switch (epk) {                                                                                                            \
-        case 0: CH_GO(conv3x3_halo2_kernel<Epi<bf16>, UP, PROF, 0>) break;                                                     \
-        case 1: CH_GO(conv3x3_halo2_kernel<Epi<bf16>, UP, PROF, 1>) break;                                                     \
-        case 3: if constexpr (!UP) { CH_GO(conv3x3_halo2_kernel<Epi<bf16>, false, PROF, 3>) } break;                           \
-        case 4: if constexpr (!UP) { CH_GO(conv3x3_halo2_kernel<Epi<bf16>, false, PROF, 4>) } break;                           \
-        default: CH_GO(conv3x3_halo2_kernel<Epi<bf16>, UP, PROF, -1>) break;                                                   \
-    }
-    if (mode == 13) { C2_EPK(false, true) }
-    else if (mode == 3) { if (a.up) { C2_EPK(true, false) } else { C2_EPK(false, false) } }
-    else if (mode == 2) { if (a.up) CH_GO(conv3x3_halo_kernel<Epi<bf16>, false, true>) else CH_GO(conv3x3_halo_kernel<Epi<bf16>, false, false>) }
-    else if (mode == 11) { CH_EPK(true, false, true, 2) }
-    else if (mode == 12) { CH_EPK(true, false, true, 3) }
-    else if (mode == 14) { CH_GO(conv3x3_halo_kernel<Epi<bf16>, true, false, true, 2, 0, 1>) }      // TEMP
-    else if (mode == 4) { if (a.up) { CH_EPK(true, true, false, 3) } else { CH_EPK(true, false, false, 3) } }
-    else { if (a.up) { CH_EPK(true, true, false, 2) } else { CH_EPK(true, false, false, 2) } }
+    if (pg_tune->conv_halo == 2) { if (a.up) CH_GO(conv3x3_halo_kernel<Epi<bf16>, false, true>) else CH_GO(conv3x3_halo_kernel<Epi<bf16>, false, false>) }
+    else { if (a.up) { CH_EPK(true) } else { CH_EPK(false) } }
 #undef CH_EPK
-#undef C2_EPK
 #undef CH_GO
     return true;
 }

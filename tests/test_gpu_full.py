@@ -92,6 +92,44 @@ def test_vq16_fused_tail_equals_groupnorm_apply_plus_conv_out(out_dtype):
         e.close()
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_vq16_halo_convolution_fast_epilogue_equals_generic_and_im2col(mode):
+    """Round 6: conv3x3_halo_kernel's epilogue without a wait behind its first store (bias from LDS, all residual loads first; instantiations for the
+    decoder's three residual / output combinations incl. the GroupNorm partial sums) against the generic epilogue of the lock-step variant
+    (conv_halo = 2) on whole decodes (and encodes) of 2 seeded images at full size: identical pixels / indices, also on a second run (persistent tiles, padded
+    patch rows: no stale halo); the implicit-GEMM kernels (conv_halo = 0) within rounding of the GroupNorm statistics' other summation order (the convolutions
+    themselves are bit-identical: tests/test_gpu_ops.py::test_conv3x3_halo_tile_path)."""
+    from plangen_amd.config import PlanGenConfig
+    from plangen_amd.engine import Engine
+    ocfg = R.OracleCfg(n_layers=0, vocab=8)
+    W = R.make_weights(ocfg, seed=3, with_lm_head=False, with_encoder=True)
+    cfg = PlanGenConfig(n_layers=0, vocab=8)
+    has_enc = True
+    e = Engine(cfg, dtype=mode, max_rows=2, max_prompt=1, max_new=1, max_images=2, with_vq_encoder=True)
+    e.load_state_dict(W)
+    try:
+        g = torch.Generator().manual_seed(11)
+        codes = torch.randint(0, cfg.img_vocab, (2, cfg.img_tokens), generator=g).int()
+        outs, idxs = [], []
+        for halo in (1, 2, 0, 1):
+            e.set_option("conv_halo", halo)
+            img = e.vq_decode(codes)
+            outs.append(img.cpu())
+            if has_enc:
+                idxs.append(e.vq_encode(img.clamp(-1, 1)).cpu())
+        assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().std()) > 0.05
+        # fast epilogue == generic epilogue (lock-step variant) == second run, bit for bit -- pixels, and with them the GroupNorm partial sums both emit
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3])
+        assert torch.equal(idxs[0], idxs[1]) and torch.equal(idxs[0], idxs[3])
+        # the implicit-GEMM path takes its GroupNorm statistics from the stand-alone kernel (another summation order): close, not identical
+        d = (outs[0].float() - outs[2].float()).abs()
+        print(f"{mode}: halo vs implicit-GEMM decode: max |d| {d.max().item():.2e}, mean {d.mean().item():.2e}; indices equal {(idxs[0] == idxs[2]).float().mean().item():.4f}")
+        assert d.max().item() < (3e-2 if mode == "bf16" else 1e-4) and d.mean().item() < (2e-3 if mode == "bf16" else 1e-6)
+    finally:
+        e.set_option("conv_halo", 1)
+        e.close()
+
+
 def test_batch_invariance_and_pad_skipping():
     e = full_engine()
     L, T = 48, 12

@@ -26,7 +26,7 @@ def test_lds_dma_protocols_match_the_compiled_code():
     assert r["failed"] == 0
     v = r["verified"]
     assert v.get("fifo", 0) >= 4             # flash2 + three gemm256 instantiations (plain, RoPE epilogue, conv)
-    assert v.get("halo_stag", 0) == 2        # production (staggered) halo convolution, plain + upsample
+    assert v.get("halo_stag", 0) == 8        # production (staggered) halo convolution: plain (generic + 4 fast epilogues) and upsample (generic + 2)
     assert v.get("big", 0) == 2              # the 128x128 GEMM (plain / implicit-im2col loaders), two barriers per K tile
     assert v.get("halo_lock", 0) == 2        # conv_halo=2 option kernels
     assert v.get("once", 0) == 1             # conv_out halo kernel

@@ -290,7 +290,7 @@ def main():
             elif spec["kind"] in ("sk4", "sk5"):
                 continue
             elif spec["kind"] == "halo_stag":
-                # steady state of the tap loop (two K tiles per iteration): [16 fragment reads, stage W(t+2), vmcnt(2), barrier, MFMAs, barrier];
+                # steady state of the tap loop (two K tiles per iteration): [stage W(t+2) (round 6: first thing in the phase), 16 fragment reads, vmcnt(2), barrier, MFMAs, barrier];
                 # replayed behind the protocol's own prologue (halo = tile 0 as one group, W(0), W(1), vmcnt(2), two barriers)
                 pro, body = main_loop(ev)
                 flat = [e for e in ev if e[0] in ("dma", "wait", "bar", "read")]
@@ -306,7 +306,7 @@ def main():
                 synth = [("dma", None)] * 6 + [("wait", 2), ("bar", None), ("bar", None)]      # halo as one 2-instruction group + W0 + W1
                 errs, n = ([], 0) if body is None else replay(synth, body, dict(g=2, need=need, tile_cls=lambda n: 1 if n else 0,
                                                                                  slot_reuse=lambda c: 4 if c else 10 ** 6, strict=True))
-                if body is None or errs or nbar < 2 or nj not in (4, 11):
+                if body is None or errs or nbar < 2 or nj not in (4, 12):          # 12: ten patch rows x nine 4-pixel instructions over eight waves (round 6: rows padded to 36 pixels); 4: the upsample form
                     bad += 1
                     report.append(f"FAIL {fname}:{short}: " + ("; ".join(errs[:3]) if errs else f"prologue: {nbar} barrier(s) between the retiring vmcnt(2) and the first read, {nj} halo DMAs"))
                 else:
