@@ -361,6 +361,11 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     GemmA ga; ga.ptr = A; ga.lda = K;
     if (conv) { ga.kind = 1; ga.Hi = Hi; ga.Wi = Wi; ga.Cin = Cin; ga.up = up; ga.zeros = zeros; }
     GemmEpi e; e.out = o0; e.out_f32 = getenv("PG_BENCH_OUT_BF16") ? 0 : 1; e.ldc = N;      // bf16 output: timing only (verify = 0)
+    // PG_BENCH_RES=1: fp32 residual (the prefill o / down projections, the ResBlock's second convolution); PG_BENCH_BIAS=1: per-column bias (every convolution,
+    // the SigLIP linears): the epilogue's loads and what their waits cost (round 6)
+    float *rsd = nullptr, *bia = nullptr;
+    if (getenv("PG_BENCH_RES")) { hipMalloc((void**)&rsd, (long)M * N * 4); hipMemset(rsd, 0, (long)M * N * 4); e.residual = rsd; e.res_f32 = 1; }
+    if (getenv("PG_BENCH_BIAS")) { hipMalloc((void**)&bia, (long)N * 4); hipMemset(bia, 0, (long)N * 4); e.bias_n = bia; }
     float* gnp = nullptr; int gn_ns = 0;
     if (conv && getenv("PG_BENCH_GN")) {          // GroupNorm partial sums from the halo convolution's epilogue (what the VQ pipeline runs), timing only
         hipMalloc((void**)&gnp, (size_t)B * 8192 * 64 * 4);
@@ -390,7 +395,7 @@ extern "C" int pg_bench_gemm(int M, int N, int K, int Hi, int Wi, int Cin, int u
     *us_out = ms * 1000.f / iters;
     pg_tune = saved;
     const int rc = hipGetLastError() == hipSuccess ? 0 : -1;
-    hipFree(A); hipFree(Wt); hipFree(zeros); hipFree(o0); if (o1) hipFree(o1); hipFree(md); if (gnp) hipFree(gnp);
+    hipFree(A); hipFree(Wt); hipFree(zeros); hipFree(o0); if (o1) hipFree(o1); hipFree(md); if (gnp) hipFree(gnp); if (rsd) hipFree(rsd); if (bia) hipFree(bia);
     hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s);
     return rc;
 }

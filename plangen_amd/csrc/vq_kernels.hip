@@ -156,6 +156,50 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x,
         *(u32x4*)(yb + e0) = ET<TO>::pack(f);
     }
 }
+// Round 6: the same pass when a pixel's vectors divide the block (C / EPV | 256: every GroupNorm of the VQ model): a thread's channel block is then the SAME in every
+// grid-stride step, so its EPV (scale, shift) pairs are loaded once instead of four 16-byte coefficient loads + a modulo per vector, and four vectors are in flight
+// per step (all loads, then the arithmetic, then the stores).  Same arithmetic per element as gn_apply_kernel -> identical values.
+template <typename TI, typename TO, bool PRECISE>
+__global__ __launch_bounds__(256) void gn_apply4_kernel(const TI* __restrict__ x, const float* __restrict__ coef, TO* __restrict__ y, int C, int swish, long vec_per_img) {
+    constexpr int EPV = ET<TO>::EPV, U = 4;
+    const int b = blockIdx.y;
+    const int vpc = C / EPV;
+    const TI* xb = x + (long)b * vec_per_img * EPV;
+    TO* yb = y + (long)b * vec_per_img * EPV;
+    const int c0 = (int)(threadIdx.x % vpc) * EPV;                  // blockIdx.x * 256 and the grid stride are multiples of vpc
+    const float* cf = coef + (long)b * C * 2 + c0 * 2;
+    float ca[EPV], cs[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; e += 2) { const f32x4 ab = *(const f32x4*)(cf + e * 2); ca[e] = ab.x; cs[e] = ab.y; ca[e + 1] = ab.z; cs[e + 1] = ab.w; }
+    const long stride = (long)gridDim.x * 256;
+    for (long v0 = (long)blockIdx.x * 256 + threadIdx.x; v0 < vec_per_img; v0 += U * stride) {
+        u32x4 raw[U][sizeof(TI) == sizeof(TO) ? 1 : 2];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const long vi = v0 + k * stride;
+            if (vi < vec_per_img) {
+                raw[k][0] = *(const u32x4*)(xb + vi * EPV);
+                if constexpr (sizeof(TI) != sizeof(TO)) raw[k][1] = *(const u32x4*)(xb + vi * EPV + 4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const long vi = v0 + k * stride;
+            if (vi < vec_per_img) {
+                float f[EPV];
+                if constexpr (sizeof(TI) == sizeof(TO)) ET<TI>::unpack(raw[k][0], f);
+                else { ET<float>::unpack(raw[k][0], f); ET<float>::unpack(raw[k][1], f + 4); }
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    float t = fmaf(f[e], ca[e], cs[e]);
+                    if (swish) t = PRECISE ? t / (1.f + expf(-t)) : t * __frcp_rn(1.f + __expf(-t));
+                    f[e] = t;
+                }
+                *(u32x4*)(yb + vi * EPV) = ET<TO>::pack(f);
+            }
+        }
+    }
+}
 template <typename TI, typename TO>
 void launch_gn_apply(hipStream_t s, const TI* x, const float* coef, TO* y, int B, int HW, int C, int swish) {
     const long vec_per_img = (long)HW * C / ET<TO>::EPV;
@@ -163,7 +207,11 @@ void launch_gn_apply(hipStream_t s, const TI* x, const float* coef, TO* y, int B
     const int cap = 4096 / (B > 0 ? B : 1) + 1;
     if (blocks > cap) blocks = cap;
     constexpr bool PRECISE = std::is_same<TO, float>::value;
-    hipLaunchKernelGGL((gn_apply_kernel<TI, TO, PRECISE>), dim3(blocks, B), dim3(256), 0, s, x, coef, y, C, swish, vec_per_img);
+    const int vpc = C / ET<TO>::EPV;
+    if (vpc > 0 && C % ET<TO>::EPV == 0 && 256 % vpc == 0)
+        hipLaunchKernelGGL((gn_apply4_kernel<TI, TO, PRECISE>), dim3(blocks, B), dim3(256), 0, s, x, coef, y, C, swish, vec_per_img);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<TI, TO, PRECISE>), dim3(blocks, B), dim3(256), 0, s, x, coef, y, C, swish, vec_per_img);
 }
 template void launch_gn_apply<float, float>(hipStream_t, const float*, const float*, float*, int, int, int, int);
 template void launch_gn_apply<float, bf16>(hipStream_t, const float*, const float*, bf16*, int, int, int, int);
