@@ -243,6 +243,9 @@ SPECS = [
                                                              "halo + W(0) retired two barriers before the first read")),
     ("conv_halo", r"conv3x3_halo_kernelI.*Lb0ELb[01]E", dict(kind="halo_lock", why="conv_halo=2 option (lock-step waves): vmcnt(4) + two barriers per K tile")),
     ("bench_kernels", r"dma_order_kernel", dict(kind="probe", why="measurement probe (tools/dma_order_probe.py), not on the product path")),
+    ("conv_halo", r"conv3x3_out2_kernel", dict(kind="fifo", g=7, need="all", tile_cls=lambda n: 0, slot_reuse=lambda c: 2, strict=True,
+                                               why="conv_out, 4 x 32 tiles: two patches ping-pong (7 DMA instructions per wave and tile); vmcnt(7 + Cout) + two barriers retire a patch "
+                                                   "before its first read, a barrier behind the last read frees it for the fill after next")),
     ("conv_halo", r"conv3x3_out_halo_kernel", dict(kind="once", why="halo patch staged once per tile (conv_out, 128 -> 3 channels)")),
     ("bench_kernels", r"weight_prefetch_kernel", dict(kind="sink", why="background-load stressor of libplangen_diag.so (round 4's run-ahead weight prefetcher): the 1 KiB per-wave LDS sink is written by LDS-DMA and never read")),
     ("chain", r"chain_skel_kernel", dict(kind="probe", why="measured skeleton of the persistent decode chain (tools/chain_skel.py), not on the product path: gathers behind vmcnt(0) + s_barrier, LDS read is a stand-in")),
@@ -280,6 +283,7 @@ def main():
                 if sp["need"] is None: sp["need"] = gemm256_need_factory()
                 elif sp["need"] == "ph2": sp["need"] = gemm256_ph2_need_factory()
                 elif sp["need"] == "bw": sp["need"] = gemm_bw_need_factory()
+                elif sp["need"] == "all": sp["need"] = lambda i, cls: i if cls == "ds_read_b128" else None     # every fragment read of iteration i needs patch i (the weights were written by ds_write, retired before the loop)
                 errs, n = replay(pro, body, sp)
                 if errs:
                     bad += 1
