@@ -217,7 +217,7 @@ int pg_get_class_timing(pg_handle h, int cls, const char** name, double* ms_sum,
  *     gemm256 (1)            256x256 MFMA GEMM for large shapes (0: 128x128 kernel everywhere; 4 / 5 / 6 pin the tile height to 256 / 224 / 192 rows
  *                            instead of choosing it per launch; +8 = four phases per K tile instead of two).  Bit-identical results in every form.
  *   VQ-16
- *     conv_halo (1)          direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant, 0: implicit-GEMM kernel)
+ *     conv_halo (1)          direct halo-tile 3x3 convolution for Cin=Cout=128 (2: lock-step variant with the generic epilogue and the one-patch conv_out, 0: implicit-GEMM kernel)
  *     vq_mid_bf16 (1)        bf16 mode: the tensor between a ResnetBlock's two convolutions is bf16 (statistics from the fp32
  *                            accumulators); 0 keeps it fp32 like the skip stream
  *     vq_tail_fused (0)      1 = decoder tail conv_out(swish(norm_out(h))) (vq_model.py:210-214) in one pass over the fp32 skip stream instead of a GroupNorm
