@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const bf16* __restric
         const int tile_id = tix;                                        // (image, tile) index of THIS tile
         tix += G;
         if constexpr (fast) {
-            const long trow0 = __builtin_amdgcn_readfirstlane((int)(((long)b * H + y0) * Wd + x0 >> 31)) * (1L << 31) + __builtin_amdgcn_readfirstlane((int)((((long)b * H + y0) * Wd + x0) & 0x7fffffff));
+            const long trow0 = ((long)b * H + y0) * Wd + x0;            // first pixel of the tile: wave-uniform (b, y0, x0 come from the tile index)
             int lrow = wr * 2 * Wd + lr;
             asm volatile("" : "+v"(lrow));                            // the 8 per-lane byte offsets are recomputed per tile instead of living (as 64-bit values) through the MFMA loop
             f32x4 bias[4], rres[4][4];
@@ -400,7 +400,8 @@ bool conv_halo_try(hipStream_t s, const GemmA& a, const bf16* W, const GemmEpi& 
     int epk = -1;
     {
         const long ldr = e.ldr ? e.ldr : e.ldc;
-        const bool vec_host = ((e.ldc | ldr) & 3) == 0 && (N & 3) == 0 && e.ldc < (1 << 20) && ldr < (1 << 20);
+        const long ldmax = e.ldc > ldr ? e.ldc : ldr;
+        const bool vec_host = ((e.ldc | ldr) & 3) == 0 && (N & 3) == 0 && (long)(CH_TH * Wd + 2 * CH_TW) * ldmax * 4 < (1L << 31);      // the fast epilogue's 32-bit byte offsets inside a tile
         const int res = !e.residual ? 0 : e.res_f32 ? 1 : 2;
         if (vec_host && e.bias_n && !e.bias_m && e.act == 0) {
             const int k = res * 2 + (e.out_f32 ? 1 : 0);
