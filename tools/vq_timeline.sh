@@ -18,7 +18,7 @@ namec = "name" if "name" in cols else "kernel_name"
 rows = list(db.execute(f"select {namec}, start, end from {v} order by start"))
 # the last decode = from the last vq_gather kernel to the last conv3x3_out_halo
 gi = max(i for i, r in enumerate(rows) if "vq_gather" in r[0])
-oi = max(i for i, r in enumerate(rows) if "conv3x3_out_halo" in r[0] or "conv3x3_small" in r[0] or "conv3x3_out_gn" in r[0])
+oi = max(i for i, r in enumerate(rows) if "conv3x3_out" in r[0] or "conv3x3_small" in r[0])
 seg = rows[gi:oi + 1]
 def short(n):
     n = re.sub(r"^_Z\d+", "", n); return n[:64]
